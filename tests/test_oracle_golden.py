@@ -1,0 +1,137 @@
+"""The CPU oracle against the fixtures captured from the reference's modules.
+
+Tolerances: frontend pre-rounding fp32 is bit-exact (same torch FFT);
+model outputs <= 1e-6 max-abs on probabilities / 2e-5 on logits (different
+summation order than torch's fused MHA/linear kernels, fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppg_oracle as O
+from ppgs_amd import weights as W
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+@pytest.fixture(scope='module')
+def state():
+    return W.seeded_state_dict(seed=1234)
+
+
+@pytest.fixture(scope='module')
+def sharp():
+    return W.seeded_state_dict(seed=4321, sharpen=2.0)
+
+
+def test_mel_basis_matches_reference_stub(golden):
+    basis = O.mel_basis()
+    ref = golden('g0_mel_basis')['basis']
+    assert basis.shape == (80, 513) and basis.dtype == np.float32
+    assert np.array_equal(basis, ref)
+    # numbers recorded in SURVEY.md 8(c)
+    assert (basis != 0).sum() == 1001
+    assert abs(float(basis.sum()) - 5.11866) < 1e-4
+    np.testing.assert_allclose(
+        basis[0, 1:5], [0.01126728, 0.02253456, 0.01990499, 0.00863771],
+        rtol=1e-6)
+
+
+def test_frontend_bit_exact(golden):
+    g = golden('g1_frontend')
+    audio = t(g['audio'])
+    assert np.array_equal(O.spectrogram_fp32(audio).numpy(), g['spec32'])
+    assert np.array_equal(O.spectrogram(audio).numpy(), g['spec16'])
+    assert np.array_equal(O.mel_from_audios(audio).numpy(), g['mel16'])
+    assert np.array_equal(
+        O.mel_from_audios(t(g['ragged_audio'])).numpy(), g['ragged_mel16'])
+
+
+def test_frontend_silence(golden):
+    g = golden('g1_frontend_silence')
+    out = O.mel_from_audios(t(g['audio'])).numpy()
+    assert out.shape == (1, 80, 10)
+    assert np.array_equal(out, g['mel16'])
+
+
+def test_single_window(golden, state, sharp):
+    g = golden('g2_single_window')
+    feats, lengths = t(g['features']), t(g['lengths'])
+    logits = O.from_features(state, feats, lengths, softmax=False).numpy()
+    assert np.abs(logits - g['logits']).max() < 2e-5
+    ppg = O.from_features(state, feats, lengths).numpy()
+    assert np.abs(ppg - g['ppg']).max() < 1e-6
+    # padded region: zero logits -> uniform
+    assert np.all(logits[1, :, 100:] == 0) and np.all(logits[2, :, 37:] == 0)
+    assert np.allclose(ppg[2, :, 37:], 1 / 40)
+    ppg = O.from_features(sharp, feats, lengths).numpy()
+    assert np.abs(ppg - g['ppg_sharp']).max() < 2e-6
+    ppg = O.from_features(state, feats, lengths, is_causal=True).numpy()
+    assert np.abs(ppg - g['ppg_causal']).max() < 1e-6
+
+
+def test_chunked(golden, state, sharp):
+    g = golden('g3_chunked')
+    for tag in 'abc':
+        feats, lengths = t(g[f'features_{tag}']), t(g[f'lengths_{tag}'])
+        ppg = O.from_features(state, feats, lengths).numpy()
+        assert ppg.shape == g[f'ppg_{tag}'].shape
+        assert np.abs(ppg - g[f'ppg_{tag}']).max() < 1e-6, tag
+    ppg = O.from_features(sharp, t(g['features_a']), t(g['lengths_a'])).numpy()
+    assert np.abs(ppg - g['ppg_a_sharp']).max() < 2e-6
+
+
+def test_halo_rule(golden, state):
+    g = golden('g4_halo')
+    feats, lengths = t(g['features']), t(g['lengths'])
+    out100 = O.from_features(state, feats, lengths).numpy()
+    assert np.abs(out100 - g['ppg_T100']).max() < 1e-6
+    out62 = O.from_features(
+        state, feats[:, :, :62], torch.tensor([62, 60])).numpy()
+    assert np.abs(out62 - g['ppg_T62']).max() < 1e-6
+    # 2 halo frames reproduce the padded-batch result; none does not
+    assert np.abs(out100[1, :, :60] - out62[1, :, :60]).max() < 1e-5
+    alone = O.from_features(state, feats[1:, :, :60], torch.tensor([60])).numpy()
+    assert np.abs(alone - g['ppg_alone']).max() < 1e-6
+    assert np.abs(alone[0] - out100[1, :, :60]).max() > 1e-3
+
+
+def test_w2v2fb_shape(golden):
+    g = golden('g5_w2v2fb')
+    state5 = W.seeded_state_dict(
+        seed=55, input_channels=768, hidden_channels=512)
+    ppg = O.from_features(state5, t(g['features']), t(g['lengths'])).numpy()
+    assert np.abs(ppg - g['ppg']).max() < 1e-6
+
+
+def test_c1_entry(golden, state):
+    g = golden('g7_c1_entry')
+    ppg = O.from_audio(state, t(g['audio'])).numpy()
+    assert ppg.shape == (1, 40, 100)
+    assert np.abs(ppg - g['ppg']).max() < 1e-6
+
+
+def test_plan_windows_rules():
+    # T=1000: windows 500,500,250; keep 400,400,200 (reference transformer.py:53-63)
+    ws = O.plan_windows(1000, [1000, 420, 30])
+    assert [w['Tc'] for w in ws] == [500, 500, 250]
+    assert [w['keep_hi'] - w['keep_lo'] for w in ws] == [400, 400, 200]
+    assert ws[0]['clens'] == [500, 470, 80]
+    assert ws[1]['clens'] == [500, 70, 0]
+    assert ws[2]['clens'] == [250, 0, 0]
+    for T in (501, 799, 800, 801, 1201, 4999):
+        ws = O.plan_windows(T, [T])
+        assert sum(w['keep_hi'] - w['keep_lo'] for w in ws) == T
+
+
+def test_packing_matches_reference_sampler(golden):
+    g = golden('g8_packing')
+    lens = g['lengths']
+    for tag, max_frames in (('32000', 32000), ('inf', float('inf'))):
+        batches = O.sampler_batches(lens, max_frames)
+        assert [len(b) for b in batches] == list(g[f'batches_{tag}_sizes'])
+        assert np.array_equal(
+            np.concatenate(batches), g[f'batches_{tag}_flat'])
+    assert len(g['batches_32000_sizes']) == 19 and len(g['batches_inf_sizes']) == 1
