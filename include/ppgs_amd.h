@@ -1,0 +1,212 @@
+/*
+ * ppgs_amd.h -- C ABI of the MI355X-native PPG inference engine.
+ *
+ * The reference (interactiveaudiolab/ppgs) has no FFI layer: its boundary is
+ * Python.  This header is the C-ABI seam a drop-in sits
+ * behind; each entry point names the reference function it replaces
+ * (paths relative to the reference checkout).  All device pointers are raw
+ * HIP device addresses on the engine's device, `stream` is a hipStream_t
+ * passed as void*.  Every function returns 0 on success or a negative
+ * PPG_E* code; ppg_last_error() returns a thread-local message.
+ * Nothing here computes on the CPU: without a HIP device the compute entry
+ * points fail with PPG_EDEVICE.
+ */
+#ifndef PPGS_AMD_H
+#define PPGS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPG_ABI_VERSION 1
+#define PPG_MAX_LAYERS 16
+
+enum {
+    PPG_OK = 0,
+    PPG_EINVAL = -1,     /* bad argument (shape, length, null pointer)        */
+    PPG_EDEVICE = -2,    /* HIP runtime error / no device                     */
+    PPG_EWORKSPACE = -3, /* workspace too small                               */
+    PPG_ELENGTH = -4,    /* legacy_mode length limit, PE table overflow
+                            (reference ppgs/model/transformer.py:46-48,103)    */
+};
+
+/* Arithmetic the encoder GEMMs run in. */
+enum {
+    PPG_PRECISION_FP32 = 0, /* f32-input MFMA, parity mode (<=1e-4 vs oracle)  */
+    PPG_PRECISION_BF16 = 1, /* bf16 MFMA, fp32 accumulate, throughput mode     */
+};
+
+/* dtype tags for feature tensors handed to ppg_encode */
+enum { PPG_DTYPE_F16 = 0, PPG_DTYPE_F32 = 1 };
+
+/* Kernel classes for ppg_engine_profile_read */
+enum {
+    PPG_K_GATHER = 0,
+    PPG_K_INCONV = 1,
+    PPG_K_QKV = 2,
+    PPG_K_ATTENTION = 3,
+    PPG_K_OUTPROJ_LN = 4,
+    PPG_K_FFN = 5,
+    PPG_K_OUTCONV_SOFTMAX = 6,
+    PPG_K_FRONTEND = 7,
+    PPG_K_COUNT = 8,
+};
+
+/*
+ * Model geometry: constructor arguments of the reference network,
+ * ppgs/model/transformer.py:15-43 (+ torch TransformerEncoderLayer defaults:
+ * ffn 2048, ReLU, post-norm, eps 1e-5) and the chunking constants
+ * ppgs/config/defaults.py:158-161.
+ */
+typedef struct PpgConfig {
+    int32_t input_channels;  /* 80 (mel) / 768 (w2v2fb)                       */
+    int32_t hidden_channels; /* 256 / 512; multiple of 64                     */
+    int32_t num_layers;      /* 5                                             */
+    int32_t ffn_channels;    /* 2048                                          */
+    int32_t output_channels; /* 40                                            */
+    int32_t kernel_size;     /* 5                                             */
+    int32_t heads;           /* 2; hidden/heads must be 128 or 256            */
+    int32_t is_causal;       /* config/causal_transformer.py:18               */
+    int32_t max_positions;   /* 5000 rows in position.encoding                */
+    int32_t chunk_length;    /* 500                                           */
+    int32_t chunk_overlap;   /* 50                                            */
+    int32_t precision;       /* PPG_PRECISION_*                               */
+} PpgConfig;
+
+/*
+ * Host pointers to fp32 arrays in the reference checkpoint layout
+ * (state_dict of ppgs.model.Transformer, ppgs/load.py:74-79; key list in
+ * SURVEY.md 8(b)).  Copied to the device (and re-packed) by
+ * ppg_engine_create; the caller may free them afterwards.
+ */
+typedef struct PpgWeights {
+    const float* position_encoding;           /* (max_positions, H)           */
+    const float* input_weight;                /* (H, Cin, 5)                  */
+    const float* input_bias;                  /* (H)                          */
+    const float* in_proj_weight[PPG_MAX_LAYERS];  /* (3H, H) rows [q;k;v]     */
+    const float* in_proj_bias[PPG_MAX_LAYERS];    /* (3H)                     */
+    const float* out_proj_weight[PPG_MAX_LAYERS]; /* (H, H)                   */
+    const float* out_proj_bias[PPG_MAX_LAYERS];   /* (H)                      */
+    const float* linear1_weight[PPG_MAX_LAYERS];  /* (F, H)                   */
+    const float* linear1_bias[PPG_MAX_LAYERS];    /* (F)                      */
+    const float* linear2_weight[PPG_MAX_LAYERS];  /* (H, F)                   */
+    const float* linear2_bias[PPG_MAX_LAYERS];    /* (H)                      */
+    const float* norm1_weight[PPG_MAX_LAYERS];    /* (H)                      */
+    const float* norm1_bias[PPG_MAX_LAYERS];
+    const float* norm2_weight[PPG_MAX_LAYERS];
+    const float* norm2_bias[PPG_MAX_LAYERS];
+    const float* output_weight;               /* (40, H, 5)                   */
+    const float* output_bias;                 /* (40)                         */
+} PpgWeights;
+
+/*
+ * One window of the chunk plan: an independent <=chunk_length-frame forward
+ * of reference Transformer.forward's recursion (transformer.py:49-64).
+ */
+typedef struct PpgWindow {
+    int32_t item;     /* batch row                                            */
+    int32_t chunked;  /* 1: source frame of window column t is
+                            max(start + t - overlap, 0) (left replicate pad);
+                         0: source frame = t                                   */
+    int32_t start;    /* window start in the replicate-padded sequence         */
+    int32_t frames;   /* Tc, window length (<= chunk_length)                   */
+    int32_t valid;    /* per-item valid frames inside the window (mask length) */
+    int32_t keep_lo;  /* window columns [keep_lo, keep_hi) go to the output    */
+    int32_t keep_hi;
+    int32_t out_frame;/* output frame of window column keep_lo                 */
+    int32_t tok_off;  /* first row of the window in the token-major buffers    */
+    int32_t vt_off;   /* first column of the window in the transposed-V buffer */
+    int32_t pad0, pad1;
+} PpgWindow;
+
+typedef struct PpgPlanInfo {
+    int32_t num_windows;     /* windows that are computed (valid > 0)          */
+    int32_t skipped_windows; /* windows whose item is exhausted (all-masked)   */
+    int32_t tokens;          /* rows of the token-major buffers (padded)       */
+    int32_t vt_tokens;       /* columns of the transposed-V buffer (padded)    */
+    int64_t processed_frames;/* sum of window lengths (unpadded)               */
+    int64_t attention_pairs; /* sum of Tc^2 over computed windows              */
+    size_t workspace_bytes;  /* what ppg_encode needs                          */
+} PpgPlanInfo;
+
+typedef struct PpgEngine PpgEngine;
+
+const char* ppg_last_error(void);
+int ppg_abi_version(void);
+
+/*
+ * Engine = one loaded model on one device; replaces the per-(representation,
+ * checkpoint) cache of ppgs.infer (ppgs/core.py:565-583) and ppgs.load.model
+ * (ppgs/load.py:33-81, the state_dict -> module step).
+ */
+int ppg_engine_create(const PpgConfig* config, const PpgWeights* weights,
+                      int device, PpgEngine** engine);
+void ppg_engine_destroy(PpgEngine* engine);
+
+/*
+ * Chunk planner, host only (usable without a device): the window list of
+ * reference Transformer.forward (transformer.py:49-64) for a (B, C, T) batch
+ * with per-item lengths.  `legacy_mode` = one window over the whole sequence
+ * (transformer.py:46-48).  Writes up to max_windows entries (all windows,
+ * skipped ones included with tok_off = -1) and returns the total count, or a
+ * negative error.  `engine` may be NULL: then chunk 500 / overlap 50.
+ */
+int ppg_plan_windows(const PpgEngine* engine, int batch, int frames,
+                     const int64_t* lengths_host, int legacy_mode,
+                     PpgWindow* windows, int max_windows, PpgPlanInfo* info);
+
+/* Workspace (device bytes) ppg_encode needs for this batch. */
+int ppg_workspace_bytes(const PpgEngine* engine, int batch, int frames,
+                        const int64_t* lengths_host, int legacy_mode,
+                        size_t* bytes);
+
+/*
+ * The forward pass: replaces ppgs.from_features -> ppgs.infer ->
+ * Transformer.forward -> softmax(dim=1) (ppgs/core.py:72-128, 551-596;
+ * ppgs/model/transformer.py:45-81).
+ *   features : device, (batch, input_channels, frames), fp16 or fp32
+ *   lengths  : HOST int64[batch] valid frames per row (1 <= len <= frames)
+ *   out      : device fp32 (batch, output_channels, frames); posteriors if
+ *              softmax != 0, else logits.  Frames >= length hold the
+ *              reference's values there (zero logits -> uniform 1/40).
+ *   workspace: device scratch of >= ppg_workspace_bytes, 256-B aligned
+ */
+int ppg_encode(PpgEngine* engine, const void* features, int feature_dtype,
+               const int64_t* lengths_host, int batch, int frames,
+               int softmax, int legacy_mode, float* out,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Frontend: replaces ppgs.preprocess.spectrogram.from_audios
+ * (ppgs/preprocess/spectrogram.py:14-50) and ppgs.preprocess.mel.from_audios
+ * (ppgs/preprocess/mel.py:14-19, 56-76).
+ *   audio: device fp32 (batch, samples) rows already zero-extended to the
+ *          batch's sample count (reference ppgs/data/collate.py:20-27)
+ *   spec : device fp16 (batch, 513, samples/160) or NULL
+ *   mel  : device fp16 (batch, 80, samples/160) or NULL
+ * samples must be > 432 (reflect padding) -- same limit as torch's
+ * reflection pad in the reference.
+ */
+int ppg_frontend(int device, const float* audio, int batch, int samples,
+                 void* spec, void* mel, void* stream);
+
+/*
+ * Per-kernel-class timing with HIP events on the launch stream (used by
+ * bench.py's roofline leg).  Enable, run, then read: total milliseconds and
+ * launch count accumulated since the last reset.  Reading synchronises the
+ * recorded events.
+ */
+int ppg_engine_profile(PpgEngine* engine, int enable);
+int ppg_engine_profile_read(PpgEngine* engine, int kernel_class,
+                            double* total_ms, int64_t* launches);
+int ppg_engine_profile_reset(PpgEngine* engine);
+int ppg_frontend_profile(int device, int enable);
+int ppg_frontend_profile_read(int device, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPGS_AMD_H */

@@ -1,0 +1,294 @@
+"""Public inference API: same names and argument meaning as the reference's
+``ppgs/core.py`` (from_audio :22, from_features :72, from_file :131,
+from_file_to_file :171, from_files_to_files :207, from_dataloader :280,
+infer :551, resample :599), executed by the HIP engine.
+
+Differences that a drop-in user should know (also in INTEGRATION.md):
+* ``gpu=None`` means "the current HIP device" (the reference runs on the CPU
+  there); this engine has no CPU path and raises if no GPU is visible.
+* Outputs are fp32 posteriors on the selected GPU, layout (batch, 40, frames).
+* ``from_audio`` accepts batch > 1 (all rows full length); the reference
+  raises there (core.py:60).
+"""
+import contextlib
+import math
+import os
+import warnings
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+from . import config, data, engine, load, preprocess
+
+# Arithmetic of the encoder GEMMs: 'bf16' (throughput; the reference's shipped
+# inference runs under autocast, ppgs/core.py:586) or 'fp32' (parity mode).
+PRECISION = os.environ.get('PPGS_AMD_PRECISION', 'bf16')
+
+# Frame budget of one padded batch when the caller leaves max_frames at the
+# reference default of infinity (which would put every file in one batch).
+DEFAULT_BATCH_FRAMES = 262144
+
+_engines = {}
+
+
+###############################################################################
+# Device / engine selection
+###############################################################################
+
+
+def device_for(gpu=None, tensor=None):
+    if not torch.cuda.is_available():
+        raise engine.PpgError(
+            'ppgs_amd: no HIP device visible; the engine has no CPU path')
+    if gpu is not None:
+        return torch.device('cuda', int(gpu))
+    if tensor is not None and tensor.is_cuda:
+        return tensor.device
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def engine_for(representation=None, checkpoint=None, gpu=None, precision=None,
+               is_causal=None):
+    """Cached engine per (representation, checkpoint, device, precision,
+    causal) -- the model cache of reference ppgs.infer (core.py:565-583)."""
+    device = device_for(gpu)
+    precision = precision or PRECISION
+    is_causal = config.IS_CAUSAL if is_causal is None else bool(is_causal)
+    ckpt_key = id(checkpoint) if isinstance(checkpoint, dict) else str(checkpoint)
+    key = (str(representation), ckpt_key, device.index, precision, is_causal)
+    if key not in _engines:
+        state = load.state_dict(checkpoint, representation)
+        _engines[key] = (engine.Engine(
+            state, device=device.index, precision=precision,
+            is_causal=is_causal), checkpoint)
+    return _engines[key][0]
+
+
+def clear_cache():
+    _engines.clear()
+
+
+###############################################################################
+# Application programming interface
+###############################################################################
+
+
+def from_audio(audio, sample_rate, representation=config.REPRESENTATION,
+               checkpoint=None, gpu=None, legacy_mode=False):
+    """Infer ppgs from audio (reference ppgs/core.py:22-69).
+
+    audio (batch, 1, samples) -> (batch, 40, samples // 160)
+    """
+    features = preprocess.from_audio(
+        audio=audio, sample_rate=sample_rate, representation=representation,
+        gpu=gpu)
+    lengths = torch.full(
+        (features.shape[0],), features.shape[-1], dtype=torch.long)
+    return from_features(
+        features=features, lengths=lengths, representation=representation,
+        checkpoint=checkpoint, gpu=gpu, legacy_mode=legacy_mode)
+
+
+def from_features(features, lengths, representation=config.REPRESENTATION,
+                  checkpoint=None, gpu=None, softmax=True, legacy_mode=False):
+    """Infer ppgs from input features (reference ppgs/core.py:72-128).
+
+    features (batch, channels, frames), lengths (batch,) ->
+    (batch, 40, frames) posteriors (logits when softmax=False)
+    """
+    device = device_for(gpu, features)
+    return infer(
+        features=features.to(device), lengths=lengths,
+        representation=representation, checkpoint=checkpoint,
+        softmax=softmax, legacy_mode=legacy_mode)
+
+
+def from_file(file, representation=config.REPRESENTATION, checkpoint=None,
+              gpu=None, legacy_mode=False):
+    """Infer ppgs from an audio file -> (40, frames)
+    (reference ppgs/core.py:131-168)."""
+    audio = load.audio(file)
+    return from_audio(
+        audio=audio[None] if audio.dim() == 2 else audio,
+        sample_rate=config.SAMPLE_RATE, representation=representation,
+        checkpoint=checkpoint, gpu=gpu, legacy_mode=legacy_mode).squeeze(0)
+
+
+def from_file_to_file(audio_file, output_file,
+                      representation=config.REPRESENTATION, checkpoint=None,
+                      gpu=None, legacy_mode=False):
+    """Infer ppg from an audio file and save a torch tensor file
+    (reference ppgs/core.py:171-204)."""
+    result = from_file(
+        file=audio_file, checkpoint=checkpoint, representation=representation,
+        gpu=gpu, legacy_mode=legacy_mode)
+    torch.save(result.detach().cpu(), output_file)
+
+
+def from_files_to_files(audio_files, output_files,
+                        representation=config.REPRESENTATION, checkpoint=None,
+                        num_workers=0, gpu=None,
+                        max_frames=config.MAX_INFERENCE_FRAMES,
+                        legacy_mode=False):
+    """Infer ppgs from audio files and save to torch tensor files
+    (reference ppgs/core.py:207-272).
+
+    num_workers == 0: one file at a time (batch 1), as the reference.
+    num_workers > 0: files are length-sorted and packed into padded batches
+    with ``len(batch) * longest <= max_frames``; ``num_workers // 2`` threads
+    decode audio and ``num_workers // 2`` threads write results.
+    """
+    if len(audio_files) != len(output_files):
+        raise ValueError('audio_files and output_files must pair one-to-one')
+    if num_workers == 0:
+        for audio_file, output_file in zip(audio_files, output_files):
+            from_file_to_file(
+                audio_file, output_file, representation=representation,
+                checkpoint=checkpoint, gpu=gpu, legacy_mode=legacy_mode)
+        return
+    dataloader = loader(
+        audio_files, num_workers=max(num_workers // 2, 1),
+        max_frames=max_frames)
+    mapping = dict(zip(audio_files, output_files))
+    from_dataloader(
+        dataloader=dataloader, output_files=mapping,
+        representation=representation, checkpoint=checkpoint,
+        save_workers=num_workers // 2, gpu=gpu, legacy_mode=legacy_mode)
+
+
+###############################################################################
+# Batched file pipeline
+###############################################################################
+
+
+class loader:
+    """Iterable of (audios (B,1,maxlen), lengths (B,), audio_files) batches;
+    counterpart of reference ppgs.data.loader with
+    features=['audio','length','audio_file'] (ppgs/data/loader.py:20-43)."""
+
+    def __init__(self, audio_files, num_workers=1,
+                 max_frames=config.MAX_INFERENCE_FRAMES, mode='sorted'):
+        self.files = list(audio_files)
+        frames = []
+        for file in self.files:
+            samples, rate = load.info(file)
+            frames.append(data.frames_of(samples, rate))
+        budget = max_frames
+        keep = data.filter_lengths(frames, budget, self.files)
+        self.files = [self.files[i] for i in keep]
+        self.frames = [frames[i] for i in keep]
+        if math.isinf(budget):
+            budget = max(DEFAULT_BATCH_FRAMES, max(self.frames, default=0))
+        self.batches = data.pack_batches(self.frames, budget, mode=mode)
+        self.num_workers = max(int(num_workers), 1)
+        self.dataset = self.files          # len(dataloader.dataset) as in the reference
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        with ThreadPoolExecutor(self.num_workers) as pool:
+            pending = None
+            for batch in self.batches + [None]:
+                upcoming = None
+                if batch is not None:
+                    upcoming = (batch, [
+                        pool.submit(load.audio, self.files[i]) for i in batch])
+                if pending is not None:
+                    indices, futures = pending
+                    audios = [f.result()[:1] for f in futures]
+                    padded, lengths = data.collate(audios)
+                    yield padded, lengths, tuple(self.files[i] for i in indices)
+                pending = upcoming
+
+
+def from_dataloader(dataloader, output_files,
+                    representation=config.REPRESENTATION, checkpoint=None,
+                    save_workers=1, gpu=None, legacy_mode=False):
+    """Infer ppgs from a dataloader yielding (audio, length, filename) batches
+    (reference ppgs/core.py:280-391): frontend on the padded batch, forward,
+    then each item truncated to length // 160 frames and saved."""
+    pool = ThreadPoolExecutor(save_workers) if save_workers > 0 else None
+    pending = []
+    try:
+        for audios, lengths, audio_files in dataloader:
+            frame_lengths = lengths // config.HOPSIZE
+            if representation != 'mel':
+                raise ValueError(
+                    f'from_dataloader supports the mel representation, '
+                    f'got {representation!r}')
+            features = preprocess.mel.from_audios(audios, lengths, gpu=gpu)
+            result = from_features(
+                features=features, lengths=frame_lengths,
+                representation=representation, checkpoint=checkpoint, gpu=gpu,
+                legacy_mode=legacy_mode).cpu()
+            filenames = [output_files[file] for file in audio_files]
+            for ppg, filename, length in zip(result, filenames, frame_lengths):
+                if pool is not None:
+                    pending.append(pool.submit(
+                        preprocess.save_masked, ppg, filename, int(length)))
+                else:
+                    preprocess.save_masked(ppg, filename, int(length))
+            # back-pressure on the save queue (reference core.py:364-365)
+            while len(pending) > 100:
+                pending.pop(0).result()
+    finally:
+        for future in pending:
+            future.result()
+        if pool is not None:
+            pool.shutdown()
+
+
+###############################################################################
+# Utilities
+###############################################################################
+
+
+def infer(features, lengths, representation='mel', checkpoint=None,
+          softmax=True, legacy_mode=False):
+    """Perform model inference (reference ppgs/core.py:551-596)."""
+    model = engine_for(representation, checkpoint, features.device.index)
+    return model.encode(
+        features, lengths, softmax=softmax, legacy_mode=legacy_mode)
+
+
+def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
+    """Perform audio resampling (reference ppgs/core.py:599-608).
+
+    Identity at 16 kHz.  Otherwise a windowed-sinc polyphase filter with
+    torchaudio.transforms.Resample's defaults (Hann window,
+    lowpass_filter_width 6, rolloff 0.99) -- restated from the published
+    algorithm; torchaudio is absent here, so this branch is parity-unpinned.
+    """
+    if sample_rate == target_rate:
+        return audio
+    orig, new = int(sample_rate), int(target_rate)
+    gcd = math.gcd(orig, new)
+    orig, new = orig // gcd, new // gcd
+    lowpass_filter_width, rolloff = 6, 0.99
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
+    kernels = (kernels * window * scale).to(torch.float32)
+    shape = audio.shape
+    flat = audio.reshape(-1, shape[-1]).to(torch.float32)
+    length = flat.shape[-1]
+    padded = torch.nn.functional.pad(flat, (width, width + orig))
+    out = torch.nn.functional.conv1d(
+        padded[:, None].to(kernels.device), kernels, stride=orig)
+    out = out.transpose(1, 2).reshape(flat.shape[0], -1)
+    target_length = math.ceil(new * length / orig)
+    return out[..., :target_length].reshape(shape[:-1] + (target_length,))
+
+
+def representation_file_extension():
+    """reference ppgs/core.py:611-621 for REPRESENTATION_KIND == 'ppg'."""
+    if config.REPRESENTATION == config.BEST_REPRESENTATION:
+        return '-ppg.pt'
+    return f'-{config.REPRESENTATION}-ppg.pt'

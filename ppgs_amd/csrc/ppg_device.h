@@ -1,0 +1,178 @@
+// Shared device-side definitions for the gfx950 kernels of the PPG engine.
+//
+// Orientation used by every matrix kernel here ("features on M, tokens on N"):
+//   out^T[n][tok] = sum_k W[n][k] * act[tok][k]
+// The weight is the MFMA A operand (16 feature rows per block, read from an
+// LDS tile shared by the workgroup's waves), the activation is the B operand
+// (16 tokens per block, held in registers by the wave that owns the tokens).
+// Both operands are K-contiguous in memory (PyTorch Linear layout W[out][in]
+// and token-major activations), so every fragment is ONE 16-byte read:
+//
+//   lane l:  idx = l & 15 (feature row of A / token of B),  g = l >> 4
+//   fragment = the 16 bytes at  [idx][kgroup*64 + g*16]   ("K-group" = 64 B)
+//
+//   bf16: 8 elements = k-slots 8g..8g+7 of one v_mfma_f32_16x16x32_bf16
+//   fp32: 4 elements, element s feeds v_mfma_f32_16x16x4_f32 number s, whose
+//         k-slot g then stands for k = 4g+s (A and B use the same bijection,
+//         so the 4 MFMAs together contract the 16 k of the group exactly once)
+//
+// The accumulator of either shape is  C[row = 4g + r][col = idx], r = 0..3:
+// a lane holds 4 consecutive FEATURES of one TOKEN -> 8/16-byte row-major
+// stores, and per-token reductions (LayerNorm, softmax over the 40 phonemes)
+// are a per-lane partial + two wavefront shuffles (xor 16, 32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/ppgs_amd.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // one 16-byte MFMA operand fragment
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    // NaN stays NaN; everything else round-to-nearest-even on bit 16
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+    return __uint_as_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_rne(lo) | ((uint32_t)f32_to_bf16_rne(hi) << 16);
+}
+
+struct PrecBF16 {
+    typedef uint16_t elem;
+    static constexpr int kBytes = 2;
+    static constexpr int KG = 32;   // elements per 64-byte K-group
+    static constexpr bool kIsBF16 = true;
+    static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+
+struct PrecF32 {
+    typedef float elem;
+    static constexpr int kBytes = 4;
+    static constexpr int KG = 16;
+    static constexpr bool kIsBF16 = false;
+    static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// Store 4 consecutive elements (fp32 values) as P::elem at dst (8/16 B aligned)
+template <class P>
+__device__ __forceinline__ void store4(void* dst, float a, float b, float c, float d) {
+    if constexpr (P::kIsBF16) {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
+    }
+}
+
+__device__ __forceinline__ float wave_sum_g(float v) {   // sum over the 4 lane groups g
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float wave_max_g(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// Epilogue kinds of linear_kernel
+enum {
+    EPI_INCONV = 0,   // +bias, zero beyond valid, +PE  -> X (fp32) [+ Xb]
+    EPI_QKV = 1,      // +bias -> Q,K row-major; V transposed (swapped MFMA operands)
+    EPI_RESLN = 2,    // +bias +residual, LayerNorm -> X [+ Xb]
+    EPI_RELU = 3,     // +bias, ReLU -> hidden (unfused FFN path)
+    EPI_OUTCONV = 4,  // +bias, mask, softmax over 40, scatter into (B,40,T)
+};
+
+struct LinearArgs {
+    const char* act;          // token-major activations
+    int lda_bytes;            // bytes per activation row
+    int taps;                 // 1 (linear) or 5 (k=5 'same' conv over window rows)
+    int groups_per_tap;       // 64-byte K-groups per tap
+    int real_groups;          // taps * groups_per_tap
+    int total_groups;         // real_groups rounded up to even (W rows zero padded)
+    const char* W;            // [N][total_groups*64 bytes]
+    const float* bias;        // [N]
+    int N;                    // padded output features
+    // outputs
+    float* X;                 // residual stream fp32 [M][H]
+    char* Xb;                 // bf16 copy of X [M][H] (bf16 mode), else null
+    int H;
+    const float* pe;          // [max_pos][H]
+    const float* gamma;
+    const float* beta;
+    char* out_rows;           // row-major output (QK / hidden), elements of P::elem
+    int out_ld;               // its row stride in elements
+    char* vt;                 // transposed V [H][vt_ld]
+    int vt_ld;
+    int v_start;              // first V feature (2H); INT_MAX when unused
+    float* out;               // (B, C, T) fp32 final output
+    int out_T;
+    int out_C;
+    int softmax;
+    const int* blk_win;       // window of each 16-token block (-1 = padding)
+    const PpgWindow* win;
+    int M;                    // rows in the token-major buffers (multiple of 16)
+};
+
+struct FfnArgs {
+    float* X;                 // residual stream, in/out
+    char* Xb;                 // act operand / bf16 copy (bf16 mode); null in fp32 mode
+    const char* W1;           // [F][H]
+    const float* b1;
+    const char* W2p;          // [H][F], k-permuted for bf16 (see pack_w2)
+    const float* b2;
+    const float* gamma;
+    const float* beta;
+    int H;
+    int F;
+    int M;
+};
+
+struct AttnItem {
+    int window;
+    int q0;                   // first query (window-relative) of the block's tile
+};
+
+struct AttnArgs {
+    const char* qk;           // [M][2H] (q | k), elements
+    int qk_ld_bytes;
+    const char* vt;           // [H][vt_ld]
+    int vt_ld_bytes;
+    char* ao;                 // [M][H] attention output (elements)
+    int H;
+    int causal;
+    float scale_log2e;        // log2(e) / sqrt(head_dim)
+    const AttnItem* items;
+    const PpgWindow* win;
+    int M;
+};
+
+struct GatherArgs {
+    const void* feats;        // (B, C, T) fp16 or fp32
+    int dtype;                // PPG_DTYPE_*
+    int C;
+    int T;
+    int overlap;
+    char* xw;                 // [M][Cp] elements
+    int Cp;
+    const int* blk_win;
+    const PpgWindow* win;
+    int M;
+};

@@ -1,0 +1,754 @@
+// Host side of the C ABI (include/ppgs_amd.h): chunk planner, weight packing,
+// plan cache, launch sequence of one encode, frontend tables, event timing.
+#include "ppg_launch.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <limits.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_OK(expr)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return fail(PPG_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+uint16_t host_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ----------------------------------------------------------------------------
+// Chunk planner (reference ppgs/model/transformer.py:49-64)
+// ----------------------------------------------------------------------------
+struct Plan {
+    std::vector<PpgWindow> all;       // every window, skipped ones with tok_off = -1
+    std::vector<PpgWindow> windows;   // computed windows (valid > 0)
+    std::vector<int> blk_win;
+    std::vector<AttnItem> items;
+    PpgPlanInfo info{};
+};
+
+int build_plan(int chunk, int overlap, int max_positions, int batch, int frames,
+               const int64_t* lengths, int legacy, int qtile, Plan* plan) {
+    if (batch <= 0 || frames <= 0 || !lengths) return fail(PPG_EINVAL, "empty batch (batch=%d frames=%d)", batch, frames);
+    for (int b = 0; b < batch; ++b)
+        if (lengths[b] < 0 || lengths[b] > frames)
+            return fail(PPG_EINVAL, "lengths[%d]=%lld outside [0, %d]", b, (long long)lengths[b], frames);
+    if (legacy && frames >= max_positions)
+        return fail(PPG_ELENGTH, "legacy_mode needs frames < %d, got %d", max_positions, frames);
+    const int stride = chunk - 2 * overlap;
+    const bool chunked = !legacy && frames > chunk;
+    const int nchunks = chunked ? (frames + stride - 1) / stride : 1;
+    int tok = 0, vt = 0;
+    for (int b = 0; b < batch; ++b) {
+        int64_t rem = lengths[b];
+        for (int i = 0; i < nchunks; ++i) {
+            PpgWindow w{};
+            w.item = b;
+            w.chunked = chunked ? 1 : 0;
+            if (chunked) {
+                w.start = i * stride;
+                const int stop = std::min(w.start + chunk, frames + overlap);
+                w.frames = stop - w.start;
+                int64_t cl = std::min<int64_t>(std::max<int64_t>(rem + overlap, 0), chunk);
+                if (cl == overlap) cl = 0;
+                rem = std::max<int64_t>(rem - stride, 0);
+                w.valid = (int)cl;
+                w.keep_lo = overlap;
+                w.keep_hi = std::min(chunk - overlap, w.frames);
+                w.out_frame = i * stride;
+            } else {
+                w.start = 0;
+                w.frames = frames;
+                w.valid = (int)lengths[b];
+                w.keep_lo = 0;
+                w.keep_hi = frames;
+                w.out_frame = 0;
+            }
+            // The reference broadcasts a (B, max(valid)) mask against (B, C, Tc):
+            // positions >= valid are masked, valid never exceeds the window.
+            w.valid = std::min(w.valid, w.frames);
+            if (w.valid > 0) {
+                w.tok_off = tok;
+                w.vt_off = vt;
+                tok += round_up(w.frames, 16);
+                vt += round_up(w.frames, 32);
+                plan->info.processed_frames += w.frames;
+                plan->info.attention_pairs += (int64_t)w.frames * w.frames;
+                const int wi = (int)plan->windows.size();
+                for (int k = 0; k < round_up(w.frames, 16) / 16; ++k) plan->blk_win.push_back(wi);
+                for (int q0 = 0; q0 < w.frames; q0 += qtile) plan->items.push_back(AttnItem{wi, q0});
+                plan->windows.push_back(w);
+            } else {
+                w.tok_off = -1;
+                w.vt_off = -1;
+                plan->info.skipped_windows++;
+            }
+            plan->all.push_back(w);
+        }
+    }
+    plan->info.num_windows = (int)plan->windows.size();
+    plan->info.tokens = tok;
+    plan->info.vt_tokens = vt;
+    return PPG_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Engine
+// ----------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct DevLayer {
+    char* wqkv; float* bqkv;
+    char* wo; float* bo;
+    char* w1; float* b1;
+    char* w2; char* w2p; float* b2;
+    float *g1, *e1, *g2, *e2;
+};
+
+struct DevPlan {
+    Plan host;
+    void* buf = nullptr;
+    PpgWindow* win = nullptr;
+    int* blk_win = nullptr;
+    AttnItem* items = nullptr;
+    uint64_t stamp = 0;
+};
+
+struct Workspace {
+    size_t xw, x, xb, qk, vt, ao, hid, total;
+    int vt_ld, qk_rows;
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct PpgEngine {
+    PpgConfig cfg{};
+    int device = 0;
+    int sz = 4;           // element bytes of the GEMM operands
+    int KG = 16;          // elements per 64-byte K-group
+    int Cp = 0;           // padded input channels of the gathered features
+    int in_groups_per_tap = 0, in_total_groups = 0;
+    int out_groups_per_tap = 0, out_total_groups = 0;
+    int head_dim = 0;
+    int ffn_nt = 2;
+    bool ffn_fused = true;
+    std::vector<void*> allocs;
+    float* pe = nullptr;
+    char* w_in = nullptr; float* b_in = nullptr;
+    char* w_out = nullptr; float* b_out = nullptr;
+    std::vector<DevLayer> layers;
+    std::map<std::string, std::unique_ptr<DevPlan>> plans;
+    uint64_t plan_stamp = 0;
+    std::mutex mu;
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> events[PPG_K_COUNT];
+    size_t events_used[PPG_K_COUNT] = {0};
+
+    ~PpgEngine() {
+        (void)hipSetDevice(device);
+        for (auto& kv : plans) if (kv.second->buf) (void)hipFree(kv.second->buf);
+        for (void* p : allocs) (void)hipFree(p);
+        for (auto& v : events) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    }
+};
+
+namespace {
+
+int upload(PpgEngine* e, const void* src, size_t bytes, void** dst) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    e->allocs.push_back(p);
+    HIP_OK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = p;
+    return PPG_OK;
+}
+
+int upload_f32(PpgEngine* e, const float* src, size_t n, size_t n_pad, float** dst) {
+    std::vector<float> tmp(std::max(n, n_pad), 0.f);
+    memcpy(tmp.data(), src, n * sizeof(float));
+    return upload(e, tmp.data(), tmp.size() * sizeof(float), reinterpret_cast<void**>(dst));
+}
+
+// dst[r][c] (rows_pad x cols_pad, zero padded) = get(r, c), in the engine's element type
+template <class F>
+int upload_matrix(PpgEngine* e, int rows, int cols, int rows_pad, int cols_pad, F get, char** dst) {
+    const size_t n = (size_t)rows_pad * cols_pad;
+    if (e->sz == 2) {
+        std::vector<uint16_t> tmp(n, 0);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) tmp[(size_t)r * cols_pad + c] = host_bf16(get(r, c));
+        return upload(e, tmp.data(), n * 2, reinterpret_cast<void**>(dst));
+    }
+    std::vector<float> tmp(n, 0.f);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) tmp[(size_t)r * cols_pad + c] = get(r, c);
+    return upload(e, tmp.data(), n * 4, reinterpret_cast<void**>(dst));
+}
+
+Workspace layout(const PpgEngine* e, const PpgPlanInfo& info) {
+    Workspace w{};
+    const size_t M = info.tokens;
+    const int H = e->cfg.hidden_channels;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.qk_rows = (int)M + 64;
+    w.vt_ld = info.vt_tokens + 64;
+    w.xw = take(M * e->Cp * e->sz);
+    w.x = take(M * H * 4);
+    w.xb = take(e->sz == 2 ? M * H * 2 : 0);
+    w.qk = take((size_t)w.qk_rows * 2 * H * e->sz);
+    w.vt = take((size_t)H * w.vt_ld * e->sz);
+    w.ao = take(M * H * e->sz);
+    w.hid = take(e->ffn_fused ? 0 : M * e->cfg.ffn_channels * e->sz);
+    w.total = off;
+    return w;
+}
+
+int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int legacy, DevPlan** out) {
+    std::string key;
+    key.reserve(16 + 8 * (size_t)batch);
+    const int hdr[3] = {batch, frames, legacy};
+    key.append(reinterpret_cast<const char*>(hdr), sizeof(hdr));
+    key.append(reinterpret_cast<const char*>(lengths), sizeof(int64_t) * (size_t)batch);
+    auto it = e->plans.find(key);
+    if (it != e->plans.end()) {
+        it->second->stamp = ++e->plan_stamp;
+        *out = it->second.get();
+        return PPG_OK;
+    }
+    auto dp = std::make_unique<DevPlan>();
+    int rc = build_plan(e->cfg.chunk_length, e->cfg.chunk_overlap, e->cfg.max_positions, batch, frames,
+                        lengths, legacy, ppg::attn_query_tile(e->head_dim), &dp->host);
+    if (rc) return rc;
+    Plan& p = dp->host;
+    p.info.workspace_bytes = layout(e, p.info).total;
+    const size_t nwin = std::max<size_t>(p.windows.size(), 1);
+    const size_t o_win = 0;
+    const size_t o_blk = align_up(o_win + nwin * sizeof(PpgWindow), 256);
+    const size_t o_item = align_up(o_blk + std::max<size_t>(p.blk_win.size(), 1) * sizeof(int), 256);
+    const size_t total = align_up(o_item + std::max<size_t>(p.items.size(), 1) * sizeof(AttnItem), 256);
+    std::vector<char> staging(total, 0);
+    if (!p.windows.empty()) memcpy(staging.data() + o_win, p.windows.data(), p.windows.size() * sizeof(PpgWindow));
+    if (!p.blk_win.empty()) memcpy(staging.data() + o_blk, p.blk_win.data(), p.blk_win.size() * sizeof(int));
+    if (!p.items.empty()) memcpy(staging.data() + o_item, p.items.data(), p.items.size() * sizeof(AttnItem));
+    // bound the cache: evict the least recently used plan
+    if (e->plans.size() >= 64) {
+        auto victim = e->plans.begin();
+        for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt)
+            if (jt->second->stamp < victim->second->stamp) victim = jt;
+        HIP_OK(hipDeviceSynchronize());
+        if (victim->second->buf) (void)hipFree(victim->second->buf);
+        e->plans.erase(victim);
+    }
+    HIP_OK(hipMalloc(&dp->buf, total));
+    HIP_OK(hipMemcpy(dp->buf, staging.data(), total, hipMemcpyHostToDevice));
+    dp->win = reinterpret_cast<PpgWindow*>(static_cast<char*>(dp->buf) + o_win);
+    dp->blk_win = reinterpret_cast<int*>(static_cast<char*>(dp->buf) + o_blk);
+    dp->items = reinterpret_cast<AttnItem*>(static_cast<char*>(dp->buf) + o_item);
+    dp->stamp = ++e->plan_stamp;
+    *out = dp.get();
+    e->plans.emplace(std::move(key), std::move(dp));
+    return PPG_OK;
+}
+
+struct Timed {
+    PpgEngine* e; int cls; hipStream_t s; EventPair ev{}; bool on = false;
+    Timed(PpgEngine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
+        if (!e->profiling) return;
+        auto& pool = e->events[cls];
+        size_t& used = e->events_used[cls];
+        if (used == pool.size()) {
+            EventPair p;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            pool.push_back(p);
+        }
+        ev = pool[used++];
+        on = hipEventRecord(ev.a, s) == hipSuccess;
+    }
+    ~Timed() { if (on) (void)hipEventRecord(ev.b, s); }
+};
+
+// ----------------------------------------------------------------------------
+// Frontend tables, one set per device
+// ----------------------------------------------------------------------------
+struct Frontend {
+    bool ready = false;
+    ppg::FrontendTables tb{};
+    std::vector<void*> allocs;
+    bool profiling = false;
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+};
+std::mutex g_front_mu;
+std::map<int, Frontend> g_front;
+
+double slaney_hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+double slaney_mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+// Slaney-scale, area-normalised triangular filterbank, the algorithm of
+// librosa.filters.mel(sr=16000, n_fft=1024, n_mels=80) called at reference
+// ppgs/preprocess/mel.py:61-64; float64 arithmetic, cast to float32.
+void mel_filterbank(std::vector<float>* dense) {
+    const int n_mels = 80, n_bins = 513;
+    const double sr = 16000.0;
+    std::vector<double> mel_f(n_mels + 2);
+    const double lo = slaney_hz_to_mel(0.0), hi = slaney_hz_to_mel(sr / 2);
+    for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = slaney_mel_to_hz(lo + (hi - lo) * i / (n_mels + 1));
+    dense->assign((size_t)n_mels * n_bins, 0.f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < n_bins; ++k) {
+            const double f = k * sr / 1024.0;
+            const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double v = std::max(0.0, std::min(lower, upper)) * enorm;
+            (*dense)[(size_t)i * n_bins + k] = (float)v;
+        }
+    }
+}
+
+int frontend_for(int device, Frontend** out) {
+    std::lock_guard<std::mutex> lock(g_front_mu);
+    Frontend& f = g_front[device];
+    if (!f.ready) {
+        HIP_OK(hipSetDevice(device));
+        std::vector<float> hann(1024);
+        for (int n = 0; n < 1024; ++n) hann[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / 1024.0));
+        std::vector<float2> tw(768);
+        for (int j = 0; j < 768; ++j) {
+            const double ang = -2.0 * M_PI * j / 1024.0;
+            tw[j] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+        std::vector<float> dense;
+        mel_filterbank(&dense);
+        std::vector<int> start(80), count(80), offset(80);
+        std::vector<float> packed;
+        for (int m = 0; m < 80; ++m) {
+            int first = -1, last = -1;
+            for (int k = 0; k < 513; ++k)
+                if (dense[(size_t)m * 513 + k] != 0.f) { if (first < 0) first = k; last = k; }
+            start[m] = first < 0 ? 0 : first;
+            count[m] = first < 0 ? 0 : last - first + 1;
+            offset[m] = (int)packed.size();
+            for (int k = 0; k < count[m]; ++k) packed.push_back(dense[(size_t)m * 513 + start[m] + k]);
+        }
+        auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
+            void* p = nullptr;
+            HIP_OK(hipMalloc(&p, bytes));
+            f.allocs.push_back(p);
+            HIP_OK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+            *dst = p;
+            return PPG_OK;
+        };
+        int rc;
+        if ((rc = up(hann.data(), hann.size() * 4, (const void**)&f.tb.hann))) return rc;
+        if ((rc = up(tw.data(), tw.size() * 8, (const void**)&f.tb.twiddle))) return rc;
+        if ((rc = up(start.data(), 320, (const void**)&f.tb.mel_start))) return rc;
+        if ((rc = up(count.data(), 320, (const void**)&f.tb.mel_count))) return rc;
+        if ((rc = up(offset.data(), 320, (const void**)&f.tb.mel_offset))) return rc;
+        if ((rc = up(packed.data(), packed.size() * 4, (const void**)&f.tb.mel_weight))) return rc;
+        f.ready = true;
+    }
+    *out = &f;
+    return PPG_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+extern "C" {
+
+const char* ppg_last_error(void) { return g_error.c_str(); }
+int ppg_abi_version(void) { return PPG_ABI_VERSION; }
+
+int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, PpgEngine** out) {
+    if (!cfg || !wts || !out) return fail(PPG_EINVAL, "null argument");
+    const int H = cfg->hidden_channels, F = cfg->ffn_channels, L = cfg->num_layers, C = cfg->input_channels;
+    if (cfg->kernel_size != 5) return fail(PPG_EINVAL, "kernel_size %d unsupported (5 only)", cfg->kernel_size);
+    if (L < 0 || L > PPG_MAX_LAYERS) return fail(PPG_EINVAL, "num_layers %d outside [0,%d]", L, PPG_MAX_LAYERS);
+    if (H != 256 && H != 512) return fail(PPG_EINVAL, "hidden_channels %d unsupported (256 or 512)", H);
+    if (cfg->heads < 1 || H % cfg->heads) return fail(PPG_EINVAL, "heads %d does not divide hidden %d", cfg->heads, H);
+    const int dh = H / cfg->heads;
+    if (dh != 128 && dh != 256) return fail(PPG_EINVAL, "head dim %d unsupported (128 or 256)", dh);
+    if (F % 64 || F < 64) return fail(PPG_EINVAL, "ffn_channels %d must be a multiple of 64", F);
+    if (cfg->output_channels < 1 || cfg->output_channels > 48) return fail(PPG_EINVAL, "output_channels %d outside [1,48]", cfg->output_channels);
+    if (C < 1) return fail(PPG_EINVAL, "input_channels %d", C);
+    if (cfg->chunk_length <= 2 * cfg->chunk_overlap || cfg->chunk_length > 512)
+        return fail(PPG_EINVAL, "chunk_length %d / overlap %d unsupported", cfg->chunk_length, cfg->chunk_overlap);
+    if (cfg->precision != PPG_PRECISION_FP32 && cfg->precision != PPG_PRECISION_BF16)
+        return fail(PPG_EINVAL, "precision %d", cfg->precision);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PPG_EDEVICE, "no HIP device: the PPG engine has no CPU path");
+    if (device < 0 || device >= ndev) return fail(PPG_EDEVICE, "device %d of %d", device, ndev);
+    HIP_OK(hipSetDevice(device));
+
+    std::unique_ptr<PpgEngine> e(new PpgEngine());
+    e->cfg = *cfg;
+    e->device = device;
+    e->sz = cfg->precision == PPG_PRECISION_BF16 ? 2 : 4;
+    e->KG = 64 / e->sz;
+    e->head_dim = dh;
+    e->Cp = round_up(C, e->KG);
+    e->in_groups_per_tap = e->Cp / e->KG;
+    e->in_total_groups = round_up(5 * e->in_groups_per_tap, 2);
+    e->out_groups_per_tap = H / e->KG;
+    e->out_total_groups = round_up(5 * e->out_groups_per_tap, 2);
+    if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
+    if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
+    if (e->ffn_nt < 1 || e->ffn_nt > 3) e->ffn_nt = 2;
+
+    int rc;
+    PpgEngine* E = e.get();
+    if ((rc = upload_f32(E, wts->position_encoding, (size_t)cfg->max_positions * H, 0, &e->pe))) return rc;
+    {   // in-conv  W'[h][tap*Cp + c] = w[h][c][tap]
+        const float* w = wts->input_weight;
+        const int Cp = e->Cp;
+        rc = upload_matrix(E, H, 5 * Cp, H, e->in_total_groups * e->KG,
+                           [&](int h, int k) { const int tap = k / Cp, c = k % Cp; return c < C ? w[((size_t)h * C + c) * 5 + tap] : 0.f; },
+                           &e->w_in);
+        if (rc) return rc;
+        if ((rc = upload_f32(E, wts->input_bias, H, 0, &e->b_in))) return rc;
+    }
+    {   // out-conv W'[n][tap*H + c] = w[n][c][tap], rows padded to 48
+        const float* w = wts->output_weight;
+        rc = upload_matrix(E, cfg->output_channels, 5 * H, 48, e->out_total_groups * e->KG,
+                           [&](int n, int k) { const int tap = k / H, c = k % H; return w[((size_t)n * H + c) * 5 + tap]; },
+                           &e->w_out);
+        if (rc) return rc;
+        if ((rc = upload_f32(E, wts->output_bias, cfg->output_channels, 48, &e->b_out))) return rc;
+    }
+    e->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        DevLayer& d = e->layers[l];
+        auto plain = [&](const float* w, int rows, int cols, char** dst) {
+            return upload_matrix(E, rows, cols, rows, cols, [&](int r, int c) { return w[(size_t)r * cols + c]; }, dst);
+        };
+        if ((rc = plain(wts->in_proj_weight[l], 3 * H, H, &d.wqkv))) return rc;
+        if ((rc = plain(wts->out_proj_weight[l], H, H, &d.wo))) return rc;
+        if ((rc = plain(wts->linear1_weight[l], F, H, &d.w1))) return rc;
+        if ((rc = plain(wts->linear2_weight[l], H, F, &d.w2))) return rc;
+        {   // pack_w2: k-slot order of the fused FFN's phase-B fragments.
+            // bf16: inside each 32-wide hidden group, slot 8g + 4e + r holds
+            // hidden 16e + 4g + r (the two phase-A accumulators e of lane
+            // group g, concatenated).  fp32: natural order.
+            const float* w = wts->linear2_weight[l];
+            const bool bf = e->sz == 2;
+            rc = upload_matrix(E, H, F, H, F,
+                               [&](int r, int c) {
+                                   if (!bf) return w[(size_t)r * F + c];
+                                   const int grp = c / 32, s = c % 32, g = s / 8, ee = (s % 8) / 4, rr = s % 4;
+                                   return w[(size_t)r * F + grp * 32 + 16 * ee + 4 * g + rr];
+                               },
+                               &d.w2p);
+            if (rc) return rc;
+        }
+        if ((rc = upload_f32(E, wts->in_proj_bias[l], 3 * H, 0, &d.bqkv))) return rc;
+        if ((rc = upload_f32(E, wts->out_proj_bias[l], H, 0, &d.bo))) return rc;
+        if ((rc = upload_f32(E, wts->linear1_bias[l], F, 0, &d.b1))) return rc;
+        if ((rc = upload_f32(E, wts->linear2_bias[l], H, 0, &d.b2))) return rc;
+        if ((rc = upload_f32(E, wts->norm1_weight[l], H, 0, &d.g1))) return rc;
+        if ((rc = upload_f32(E, wts->norm1_bias[l], H, 0, &d.e1))) return rc;
+        if ((rc = upload_f32(E, wts->norm2_weight[l], H, 0, &d.g2))) return rc;
+        if ((rc = upload_f32(E, wts->norm2_bias[l], H, 0, &d.e2))) return rc;
+    }
+    *out = e.release();
+    return PPG_OK;
+}
+
+void ppg_engine_destroy(PpgEngine* engine) { delete engine; }
+
+int ppg_plan_windows(const PpgEngine* engine, int batch, int frames, const int64_t* lengths,
+                     int legacy_mode, PpgWindow* windows, int max_windows, PpgPlanInfo* info) {
+    Plan plan;
+    const int chunk = engine ? engine->cfg.chunk_length : 500;
+    const int overlap = engine ? engine->cfg.chunk_overlap : 50;
+    const int maxpos = engine ? engine->cfg.max_positions : 5000;
+    const int qt = ppg::attn_query_tile(engine ? engine->head_dim : 128);
+    int rc = build_plan(chunk, overlap, maxpos, batch, frames, lengths, legacy_mode, qt, &plan);
+    if (rc) return rc;
+    if (engine) plan.info.workspace_bytes = layout(engine, plan.info).total;
+    if (info) *info = plan.info;
+    const int n = (int)plan.all.size();
+    if (windows) for (int i = 0; i < n && i < max_windows; ++i) windows[i] = plan.all[i];
+    return n;
+}
+
+int ppg_workspace_bytes(const PpgEngine* engine, int batch, int frames, const int64_t* lengths,
+                        int legacy_mode, size_t* bytes) {
+    if (!engine || !bytes) return fail(PPG_EINVAL, "null argument");
+    PpgPlanInfo info;
+    int rc = ppg_plan_windows(engine, batch, frames, lengths, legacy_mode, nullptr, 0, &info);
+    if (rc < 0) return rc;
+    *bytes = info.workspace_bytes;
+    return PPG_OK;
+}
+
+int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int64_t* lengths,
+               int batch, int frames, int softmax, int legacy_mode, float* out,
+               void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!e || !features || !lengths || !out) return fail(PPG_EINVAL, "null argument");
+    if (feature_dtype != PPG_DTYPE_F16 && feature_dtype != PPG_DTYPE_F32) return fail(PPG_EINVAL, "feature dtype %d", feature_dtype);
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_OK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    DevPlan* dp = nullptr;
+    int rc = get_plan(e, batch, frames, lengths, legacy_mode, &dp);
+    if (rc) return rc;
+    const Plan& plan = dp->host;
+    const PpgConfig& c = e->cfg;
+    const int H = c.hidden_channels, F = c.ffn_channels, M = plan.info.tokens;
+    const int prec = c.precision;
+    const size_t out_elems = (size_t)batch * c.output_channels * frames;
+
+    // exhausted windows (all keys masked): reference output there is
+    // logits 0 -> uniform posteriors; nothing to compute.
+    if (plan.info.skipped_windows > 0 || M == 0) {
+        hipError_t he = ppg::launch_fill(out, out_elems, softmax ? 1.0f / c.output_channels : 0.f, s);
+        if (he != hipSuccess) return fail(PPG_EDEVICE, "fill: %s", hipGetErrorString(he));
+    }
+    if (M == 0) return PPG_OK;
+
+    const Workspace ws = layout(e, plan.info);
+    if (!workspace || workspace_bytes < ws.total)
+        return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, ws.total);
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(PPG_EINVAL, "workspace not 256-byte aligned");
+    char* base = static_cast<char*>(workspace);
+    char* xw = base + ws.xw;
+    float* X = reinterpret_cast<float*>(base + ws.x);
+    char* Xb = e->sz == 2 ? base + ws.xb : nullptr;
+    char* qk = base + ws.qk;
+    char* vt = base + ws.vt;
+    char* ao = base + ws.ao;
+    char* hid = base + ws.hid;
+    const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
+
+#define LAUNCH_OK(expr, what)                                                        \
+    do {                                                                             \
+        hipError_t he_ = (expr);                                                     \
+        if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
+    } while (0)
+
+    // V^T padding columns and the K rows past the last token are read (masked)
+    // by the attention tiles: keep them finite.
+    HIP_OK(hipMemsetAsync(vt, 0, (size_t)H * ws.vt_ld * e->sz, s));
+    HIP_OK(hipMemsetAsync(qk + (size_t)M * 2 * H * e->sz, 0, (size_t)64 * 2 * H * e->sz, s));
+
+    {
+        Timed t(e, PPG_K_GATHER, s);
+        GatherArgs g{};
+        g.feats = features; g.dtype = feature_dtype; g.C = c.input_channels; g.T = frames;
+        g.overlap = c.chunk_overlap; g.xw = xw; g.Cp = e->Cp;
+        g.blk_win = dp->blk_win; g.win = dp->win; g.M = M;
+        LAUNCH_OK(ppg::launch_gather(prec, g, s), "gather");
+    }
+    auto base_args = [&]() {
+        LinearArgs a{};
+        a.blk_win = dp->blk_win; a.win = dp->win; a.M = M; a.H = H;
+        a.X = X; a.Xb = Xb; a.v_start = INT_MAX; a.taps = 1;
+        return a;
+    };
+    {
+        Timed t(e, PPG_K_INCONV, s);
+        LinearArgs a = base_args();
+        a.act = xw; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
+        a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
+        a.total_groups = e->in_total_groups;
+        a.W = e->w_in; a.bias = e->b_in; a.N = H; a.pe = e->pe;
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, a, H / 256, s), "in-conv");
+    }
+    const int hg = H / e->KG;   // K-groups of a hidden-wide row
+    for (int l = 0; l < c.num_layers; ++l) {
+        const DevLayer& d = e->layers[l];
+        {
+            Timed t(e, PPG_K_QKV, s);
+            LinearArgs a = base_args();
+            a.act = act_x; a.lda_bytes = H * e->sz;
+            a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
+            a.W = d.wqkv; a.bias = d.bqkv; a.N = 3 * H;
+            a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, a, 3 * H / 256, s), "qkv");
+        }
+        {
+            Timed t(e, PPG_K_ATTENTION, s);
+            AttnArgs a{};
+            a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
+            a.ao = ao; a.H = H; a.causal = c.is_causal;
+            a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
+            a.items = dp->items; a.win = dp->win; a.M = M;
+            LAUNCH_OK(ppg::launch_attn(prec, a, (int)plan.items.size(), c.heads, e->head_dim, s), "attention");
+        }
+        {
+            Timed t(e, PPG_K_OUTPROJ_LN, s);
+            LinearArgs a = base_args();
+            a.act = ao; a.lda_bytes = H * e->sz;
+            a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
+            a.W = d.wo; a.bias = d.bo; a.N = H; a.gamma = d.g1; a.beta = d.e1;
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, a, 1, s), "out-proj+LN");
+        }
+        {
+            Timed t(e, PPG_K_FFN, s);
+            if (e->ffn_fused) {
+                FfnArgs a{};
+                a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M;
+                LAUNCH_OK(ppg::launch_ffn(prec, a, e->ffn_nt, s), "ffn");
+            } else {
+                LinearArgs a = base_args();
+                a.act = act_x; a.lda_bytes = H * e->sz;
+                a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
+                a.W = d.w1; a.bias = d.b1; a.N = F; a.out_rows = hid; a.out_ld = F;
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RELU, 16, a, F / 256, s), "ffn1");
+                LinearArgs b = base_args();
+                const int fg = F / e->KG;
+                b.act = hid; b.lda_bytes = F * e->sz;
+                b.groups_per_tap = fg; b.real_groups = fg; b.total_groups = fg;
+                b.W = d.w2; b.bias = d.b2; b.N = H; b.gamma = d.g2; b.beta = d.e2;
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, b, 1, s), "ffn2+LN");
+            }
+        }
+    }
+    {
+        Timed t(e, PPG_K_OUTCONV_SOFTMAX, s);
+        LinearArgs a = base_args();
+        a.act = act_x; a.lda_bytes = H * e->sz; a.taps = 5;
+        a.groups_per_tap = e->out_groups_per_tap; a.real_groups = 5 * e->out_groups_per_tap;
+        a.total_groups = e->out_total_groups;
+        a.W = e->w_out; a.bias = e->b_out; a.N = 48;
+        a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, a, 1, s), "out-conv+softmax");
+    }
+#undef LAUNCH_OK
+    return PPG_OK;
+}
+
+int ppg_frontend(int device, const float* audio, int batch, int samples, void* spec, void* mel, void* stream) {
+    if (!audio || (!spec && !mel)) return fail(PPG_EINVAL, "null argument");
+    if (batch <= 0) return fail(PPG_EINVAL, "batch %d", batch);
+    if (samples <= 432)
+        return fail(PPG_EINVAL, "samples %d: reflect padding of 432 needs more than 432 samples", samples);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PPG_EDEVICE, "no HIP device: the PPG frontend has no CPU path");
+    Frontend* f = nullptr;
+    int rc = frontend_for(device, &f);
+    if (rc) return rc;
+    HIP_OK(hipSetDevice(device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    EventPair ev{};
+    bool on = false;
+    if (f->profiling) {
+        if (f->events_used == f->events.size()) {
+            EventPair p;
+            HIP_OK(hipEventCreate(&p.a));
+            HIP_OK(hipEventCreate(&p.b));
+            f->events.push_back(p);
+        }
+        ev = f->events[f->events_used++];
+        on = hipEventRecord(ev.a, s) == hipSuccess;
+    }
+    hipError_t he = ppg::launch_frontend(f->tb, audio, batch, samples, spec, mel, s);
+    if (on) (void)hipEventRecord(ev.b, s);
+    if (he != hipSuccess) return fail(PPG_EDEVICE, "frontend: %s", hipGetErrorString(he));
+    return PPG_OK;
+}
+
+int ppg_engine_profile(PpgEngine* e, int enable) {
+    if (!e) return fail(PPG_EINVAL, "null engine");
+    e->profiling = enable != 0;
+    return PPG_OK;
+}
+
+int ppg_engine_profile_reset(PpgEngine* e) {
+    if (!e) return fail(PPG_EINVAL, "null engine");
+    for (auto& u : e->events_used) u = 0;
+    return PPG_OK;
+}
+
+int ppg_engine_profile_read(PpgEngine* e, int cls, double* total_ms, int64_t* launches) {
+    if (!e || cls < 0 || cls >= PPG_K_COUNT || !total_ms || !launches) return fail(PPG_EINVAL, "bad argument");
+    double total = 0;
+    for (size_t i = 0; i < e->events_used[cls]; ++i) {
+        HIP_OK(hipEventSynchronize(e->events[cls][i].b));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e->events[cls][i].a, e->events[cls][i].b));
+        total += ms;
+    }
+    *total_ms = total;
+    *launches = (int64_t)e->events_used[cls];
+    return PPG_OK;
+}
+
+int ppg_frontend_profile(int device, int enable) {
+    Frontend* f = nullptr;
+    int rc = frontend_for(device, &f);
+    if (rc) return rc;
+    f->profiling = enable != 0;
+    f->events_used = 0;
+    return PPG_OK;
+}
+
+int ppg_frontend_profile_read(int device, double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) return fail(PPG_EINVAL, "null argument");
+    Frontend* f = nullptr;
+    int rc = frontend_for(device, &f);
+    if (rc) return rc;
+    double total = 0;
+    for (size_t i = 0; i < f->events_used; ++i) {
+        HIP_OK(hipEventSynchronize(f->events[i].b));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, f->events[i].a, f->events[i].b));
+        total += ms;
+    }
+    *total_ms = total;
+    *launches = (int64_t)f->events_used;
+    return PPG_OK;
+}
+
+}  // extern "C"

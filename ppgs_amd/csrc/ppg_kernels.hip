@@ -1,0 +1,860 @@
+// gfx950 kernels of the PPG encoder: window gather, generic "weights-from-LDS"
+// linear/conv kernel with fused epilogues, fused FFN, attention.
+// See ppg_device.h for the operand orientation shared by all of them.
+#include "ppg_device.h"
+#include "ppg_launch.h"
+
+#include <limits.h>
+#include <type_traits>
+
+namespace {
+
+constexpr float kLnEps = 1e-5f;
+
+struct TokMeta {
+    int w;       // window index or -1
+    int tt;      // window-relative position
+    int frames;  // Tc
+    int valid;   // mask length
+};
+
+__device__ __forceinline__ TokMeta tok_meta(const int* blk_win, const PpgWindow* win, int m, int M) {
+    TokMeta t;
+    t.w = -1; t.tt = 0; t.frames = 0; t.valid = 0;
+    if (m < M) {
+        const int w = blk_win[m >> 4];
+        if (w >= 0) {
+            t.w = w;
+            t.tt = m - win[w].tok_off;
+            t.frames = win[w].frames;
+            t.valid = win[w].valid;
+        }
+    }
+    return t;
+}
+
+// XOR swizzle of a 16-byte slot index inside an LDS tile row; conflict-free
+// for the 16-lane service groups of ds_read_b128 when rows are 128 B (mask 7)
+// or >= 256 B (mask 15); rows of 64 B keep a 2-way conflict.
+template <int ROW_BYTES>
+__device__ __forceinline__ int swz(int row, int p) {
+    if constexpr (ROW_BYTES >= 256) return p ^ (row & 15);
+    else if constexpr (ROW_BYTES == 128) return p ^ (row & 7);
+    else return p ^ ((row >> 2) & 3);
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm(acc + bias + residual) epilogue, acc in the transposed C layout
+// (lane: token = tok0 + 16t + idx, features nb*16 + 4g + r).
+// ---------------------------------------------------------------------------
+template <class P, int NB, int NT>
+__device__ __forceinline__ void resln_epilogue(
+    f32x4 (&acc)[NB][NT], const float* __restrict__ bias, float* X, char* Xb, int H,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    int tok0, int M, int idx, int g)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = tok0 + 16 * t + idx;
+        const bool ok = m < M;
+        float* xrow = X + (size_t)(ok ? m : 0) * H;
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = nb * 16 + 4 * g;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) rv = *reinterpret_cast<const float4*>(xrow + n);
+            acc[nb][t][0] += bv.x + rv.x;
+            acc[nb][t][1] += bv.y + rv.y;
+            acc[nb][t][2] += bv.z + rv.z;
+            acc[nb][t][3] += bv.w + rv.w;
+            sum += (acc[nb][t][0] + acc[nb][t][1]) + (acc[nb][t][2] + acc[nb][t][3]);
+        }
+        const float mean = wave_sum_g(sum) / (float)H;
+        float sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[nb][t][r] - mean;
+                sq += d * d;
+            }
+        }
+        const float var = wave_sum_g(sq) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + kLnEps);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = nb * 16 + 4 * g;
+            const float4 gv = *reinterpret_cast<const float4*>(gamma + n);
+            const float4 ev = *reinterpret_cast<const float4*>(beta + n);
+            const float y0 = (acc[nb][t][0] - mean) * rstd * gv.x + ev.x;
+            const float y1 = (acc[nb][t][1] - mean) * rstd * gv.y + ev.y;
+            const float y2 = (acc[nb][t][2] - mean) * rstd * gv.z + ev.z;
+            const float y3 = (acc[nb][t][3] - mean) * rstd * gv.w + ev.w;
+            if (ok) {
+                *reinterpret_cast<float4*>(xrow + n) = make_float4(y0, y1, y2, y3);
+                if constexpr (P::kIsBF16)
+                    store4<P>(Xb + ((size_t)m * H + n) * 2, y0, y1, y2, y3);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Window gather: (B, C, T) features -> token-major Xw[M][Cp] in P::elem.
+// Applies the left replicate padding of chunked windows (reference
+// transformer.py:54) and zero-fills padded channels / padded token rows.
+// Tile = 32 channels x 64 tokens through LDS so both sides are coalesced.
+// ---------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
+    __shared__ float tile[32][65];
+    const int tok0 = blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 63;   // token within tile (read phase)
+    const int ty = threadIdx.x >> 6;   // 0..3
+    {
+        const int m = tok0 + tx;
+        const TokMeta tm = tok_meta(a.blk_win, a.win, m, a.M);
+        int frame = -1;
+        size_t base = 0;
+        if (tm.w >= 0 && tm.tt < tm.frames) {
+            const PpgWindow w = a.win[tm.w];
+            frame = w.chunked ? max(w.start + tm.tt - a.overlap, 0) : tm.tt;
+            base = (size_t)w.item * a.C * a.T;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + ty * 8 + i;
+            float v = 0.f;
+            if (frame >= 0 && c < a.C) {
+                const size_t off = base + (size_t)c * a.T + frame;
+                v = (a.dtype == PPG_DTYPE_F16)
+                        ? __half2float(reinterpret_cast<const __half*>(a.feats)[off])
+                        : reinterpret_cast<const float*>(a.feats)[off];
+            }
+            tile[ty * 8 + i][tx] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int c = threadIdx.x & 31;     // channel within tile (write phase)
+        const int tq = threadIdx.x >> 5;    // 0..7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tl = tq * 8 + i;
+            const int m = tok0 + tl;
+            if (m < a.M && c0 + c < a.Cp) {
+                const float v = tile[c][tl];
+                typename P::elem* dst = reinterpret_cast<typename P::elem*>(a.xw) + (size_t)m * a.Cp + c0 + c;
+                if constexpr (P::kIsBF16) *dst = f32_to_bf16_rne(v);
+                else *dst = v;
+            }
+        }
+    }
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Generic linear / k-tap conv:  out^T[n][tok] = sum_k W[n][k] act[tok][k].
+// Workgroup = 4 waves; wave owns 16*NT tokens, all NB*16 features of this
+// blockIdx.y pass.  W tiles [NB*16 rows][128 B = 2 K-groups] are staged
+// global -> registers -> LDS (double buffered, one barrier per tile, loads
+// of tile s+1 issued before the MFMAs of tile s).
+// ---------------------------------------------------------------------------
+template <class P, int NT, int NB, int EPI>
+__global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_BYTES = NB * 16 * 128;
+    constexpr int SLOTS = NB * 16 * 8;
+    constexpr int WR = (SLOTS + 255) / 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15;
+    const int g = lane >> 4;
+    const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
+    const int n0 = blockIdx.y * NB * 16;
+    const bool swap = (EPI == EPI_QKV) && (n0 >= a.v_start);
+
+    TokMeta tm[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tm[t] = tok_meta(a.blk_win, a.win, tok0 + 16 * t + idx, a.M);
+
+    const int pad = a.taps >> 1;
+    const char* wbase = a.W + (size_t)n0 * a.total_groups * 64;
+    const int w_row_bytes = a.total_groups * 64;
+
+    auto load_w = [&](int s, u32x4 (&wr)[WR]) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int slot = i * 256 + tid;
+            if (SLOTS % 256 == 0 || slot < SLOTS) {
+                const int row = slot >> 3, p = slot & 7;
+                wr[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)row * w_row_bytes + s * 128 + p * 16);
+            }
+        }
+    };
+    auto store_w = [&](char* buf, const u32x4 (&wr)[WR]) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int slot = i * 256 + tid;
+            if (SLOTS % 256 == 0 || slot < SLOTS) {
+                const int row = slot >> 3, p = slot & 7;
+                *reinterpret_cast<u32x4*>(buf + row * 128 + (swz<128>(row, p) << 4)) = wr[i];
+            }
+        }
+    };
+    // activation fragments of tile s (K-groups 2s, 2s+1)
+    auto load_act = [&](int s, u32x4 (&af)[2][NT]) {
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            const int gk = 2 * s + kg;
+            const int tap = gk / a.groups_per_tap;
+            const int kgi = gk - tap * a.groups_per_tap;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int st = tm[t].tt + tap - pad;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (tm[t].w >= 0 && gk < a.real_groups && st >= 0 && st < tm[t].frames) {
+                    const int m = tok0 + 16 * t + idx + tap - pad;
+                    v = *reinterpret_cast<const u32x4*>(a.act + (size_t)m * a.lda_bytes + kgi * 64 + g * 16);
+                }
+                af[kg][t] = v;
+            }
+        }
+    };
+
+    f32x4 acc[NB][NT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int steps = a.total_groups >> 1;
+    u32x4 wr[WR];
+    u32x4 acur[2][NT], anext[2][NT];
+    load_w(0, wr);
+    load_act(0, acur);
+    store_w(smem, wr);
+    __syncthreads();
+
+    // SWAP (V pass of the QKV projection) exchanges the MFMA operands so the
+    // accumulator comes out token-major-transposed; compile-time per loop.
+    auto main_loop = [&](auto swap_tag) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+        for (int s = 0; s < steps; ++s) {
+            const bool more = s + 1 < steps;
+            if (more) {
+                load_w(s + 1, wr);
+                load_act(s + 1, anext);
+            }
+            const char* buf = smem + (s & 1) * TILE_BYTES;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = nb * 16 + idx;
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(buf + row * 128 + (swz<128>(row, kg * 4 + g) << 4));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (SWAP) P::mma(acc[nb][t], acur[kg][t], wf);
+                        else P::mma(acc[nb][t], wf, acur[kg][t]);
+                    }
+                }
+            }
+            if (more) {
+                store_w(smem + ((s + 1) & 1) * TILE_BYTES, wr);
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acur[kg][t] = anext[kg][t];
+            }
+            __syncthreads();
+        }
+    };
+    if constexpr (EPI == EPI_QKV) {
+        if (swap) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+    } else {
+        main_loop(std::false_type{});
+    }
+
+    // ----------------------------- epilogues --------------------------------
+    if constexpr (EPI == EPI_RESLN) {
+        resln_epilogue<P, NB, NT>(acc, a.bias, a.X, a.Xb, a.H, a.gamma, a.beta, tok0, a.M, idx, g);
+    } else if constexpr (EPI == EPI_INCONV) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int m = tok0 + 16 * t + idx;
+            if (m >= a.M) continue;
+            const bool live = tm[t].w >= 0 && tm[t].tt < tm[t].frames;
+            const bool valid = live && tm[t].tt < tm[t].valid;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + nb * 16 + 4 * g;
+                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) {
+                    y = *reinterpret_cast<const float4*>(a.pe + (size_t)tm[t].tt * a.H + n);
+                    if (valid) {
+                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                        y.x += acc[nb][t][0] + bv.x;
+                        y.y += acc[nb][t][1] + bv.y;
+                        y.z += acc[nb][t][2] + bv.z;
+                        y.w += acc[nb][t][3] + bv.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(a.X + (size_t)m * a.H + n) = y;
+                if constexpr (P::kIsBF16) store4<P>(a.Xb + ((size_t)m * a.H + n) * 2, y.x, y.y, y.z, y.w);
+            }
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        if (!swap) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int m = tok0 + 16 * t + idx;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int n = n0 + nb * 16 + 4 * g;
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                    store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes,
+                              acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
+                              acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
+                }
+            }
+        } else {
+            // swapped operands: lane holds tokens 4g..4g+3 of block t for
+            // feature nb*16 + idx.  bf16: columns are permuted inside 32-token
+            // groups (position 8g + 4e + r, e = parity of the 16-token block)
+            // so that the PV A-fragment of attn_kernel is one 16-byte read.
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int mb = tok0 + 16 * t;            // wave-uniform block start
+                if (mb >= a.M) continue;
+                const int w = a.blk_win[mb >> 4];
+                if (w < 0) continue;
+                const int ttb = mb - a.win[w].tok_off;   // multiple of 16
+                int col;
+                if constexpr (P::kIsBF16) col = a.win[w].vt_off + (ttb >> 5) * 32 + 8 * g + 4 * ((ttb >> 4) & 1);
+                else col = a.win[w].vt_off + ttb + 4 * g;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int n = n0 + nb * 16 + idx;
+                    const float bv = a.bias[n];
+                    store4<P>(a.vt + ((size_t)(n - a.v_start) * a.vt_ld + col) * P::kBytes,
+                              acc[nb][t][0] + bv, acc[nb][t][1] + bv,
+                              acc[nb][t][2] + bv, acc[nb][t][3] + bv);
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int m = tok0 + 16 * t + idx;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + nb * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes,
+                          fmaxf(acc[nb][t][0] + bv.x, 0.f), fmaxf(acc[nb][t][1] + bv.y, 0.f),
+                          fmaxf(acc[nb][t][2] + bv.z, 0.f), fmaxf(acc[nb][t][3] + bv.w, 0.f));
+            }
+        }
+    } else if constexpr (EPI == EPI_OUTCONV) {
+        // logits = (conv + bias) * mask; per-frame softmax over the out_C
+        // phonemes: per-lane partial over (nb, r), then shuffles over g.
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool live = tm[t].w >= 0 && tm[t].tt < tm[t].frames;
+            const bool valid = live && tm[t].tt < tm[t].valid;
+            float v[NB][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + nb * 16 + 4 * g);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb * 16 + 4 * g + r;
+                    v[nb][r] = valid ? acc[nb][t][r] + bb[r] : 0.f;
+                    if (n < a.out_C) mx = fmaxf(mx, v[nb][r]);
+                }
+            }
+            if (a.softmax) {
+                mx = wave_max_g(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = nb * 16 + 4 * g + r;
+                        const float e = (n < a.out_C) ? expf(v[nb][r] - mx) : 0.f;
+                        v[nb][r] = e;
+                        sum += e;
+                    }
+                sum = wave_sum_g(sum);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nb][r] *= inv;
+            }
+            if (live) {
+                const PpgWindow w = a.win[tm[t].w];
+                if (tm[t].tt >= w.keep_lo && tm[t].tt < w.keep_hi) {
+                    const int frame = w.out_frame + (tm[t].tt - w.keep_lo);
+                    float* o = a.out + (size_t)w.item * a.out_C * a.out_T + frame;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = nb * 16 + 4 * g + r;
+                            if (n < a.out_C) o[(size_t)n * a.out_T] = v[nb][r];
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused FFN + residual + LayerNorm:
+//   X <- LN(X + W2 relu(W1 x + b1) + b2)
+// The 2048-wide hidden never leaves registers: per hidden chunk, phase A
+// computes h^T[hid][tok] (C layout: 4 consecutive hid per lane), which after
+// ReLU/bf16 packing IS the B fragment of phase B (k-slot permutation folded
+// into the host-side packing of W2, see pack_w2 in ppg_engine.hip).
+// W1/W2 chunk tiles (32 KiB each) are staged global->regs->LDS.
+// ---------------------------------------------------------------------------
+template <class P, int NT, int NBH>
+__global__ __launch_bounds__(256) void ffn_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = NBH * 16;
+    constexpr int ROW1 = H * P::kBytes;             // W1 tile row bytes
+    constexpr int XG = ROW1 / 64;                   // K-groups of x
+    constexpr int HC = 32768 / ROW1;                // hidden rows per chunk
+    constexpr int HB = HC / 16;                     // hidden 16-blocks per chunk
+    constexpr int ROW2 = HC * P::kBytes;            // W2 tile row bytes (128 or 64)
+    constexpr int HG = ROW2 / 64;                   // K-groups of phase B per chunk
+    constexpr int S1 = ROW1 / 16;                   // slots per W1 row
+    constexpr int S2 = ROW2 / 16;
+    constexpr int WR1 = 32768 / 16 / 256;           // 8
+    constexpr int WR2 = (H * ROW2) / 16 / 256;      // 8
+    char* lds1 = smem;
+    char* lds2 = smem + 32768;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15;
+    const int g = lane >> 4;
+    const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
+    const int NC = a.F / HC;
+
+    const char* actp = P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X);
+    u32x4 xf[XG][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = tok0 + 16 * t + idx;
+#pragma unroll
+        for (int kg = 0; kg < XG; ++kg) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (m < a.M) v = *reinterpret_cast<const u32x4*>(actp + (size_t)m * ROW1 + kg * 64 + g * 16);
+            xf[kg][t] = v;
+        }
+    }
+
+    auto load_tiles = [&](int c, u32x4 (&r1)[WR1], u32x4 (&r2)[WR2]) {
+        const char* src1 = a.W1 + (size_t)c * 32768;                 // HC contiguous rows
+#pragma unroll
+        for (int i = 0; i < WR1; ++i) r1[i] = *reinterpret_cast<const u32x4*>(src1 + (size_t)(i * 256 + tid) * 16);
+#pragma unroll
+        for (int i = 0; i < WR2; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / S2, p = slot % S2;
+            r2[i] = *reinterpret_cast<const u32x4*>(a.W2p + ((size_t)row * a.F + (size_t)c * HC) * P::kBytes + p * 16);
+        }
+    };
+    auto store_tiles = [&](const u32x4 (&r1)[WR1], const u32x4 (&r2)[WR2]) {
+#pragma unroll
+        for (int i = 0; i < WR1; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / S1, p = slot % S1;
+            *reinterpret_cast<u32x4*>(lds1 + row * ROW1 + (swz<ROW1>(row, p) << 4)) = r1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WR2; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / S2, p = slot % S2;
+            *reinterpret_cast<u32x4*>(lds2 + row * ROW2 + (swz<ROW2>(row, p) << 4)) = r2[i];
+        }
+    };
+
+    f32x4 yacc[NBH][NT];
+#pragma unroll
+    for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 r1[WR1], r2[WR2];
+    load_tiles(0, r1, r2);
+    store_tiles(r1, r2);
+    __syncthreads();
+
+    for (int c = 0; c < NC; ++c) {
+        const bool more = c + 1 < NC;
+        if (more) load_tiles(c + 1, r1, r2);
+
+        // phase A: h^T = W1c x^T
+        f32x4 hacc[HB][NT];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) hacc[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < XG; ++kg) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const int row = hb * 16 + idx;
+                const u32x4 wf = *reinterpret_cast<const u32x4*>(lds1 + row * ROW1 + (swz<ROW1>(row, kg * 4 + g) << 4));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) P::mma(hacc[hb][t], wf, xf[kg][t]);
+            }
+        }
+        // bias + ReLU, pack as phase-B fragments
+        u32x4 hf[HG][NT];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.b1 + c * HC + hb * 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float h0 = fmaxf(hacc[hb][t][0] + bv.x, 0.f);
+                const float h1 = fmaxf(hacc[hb][t][1] + bv.y, 0.f);
+                const float h2 = fmaxf(hacc[hb][t][2] + bv.z, 0.f);
+                const float h3 = fmaxf(hacc[hb][t][3] + bv.w, 0.f);
+                if constexpr (P::kIsBF16) {
+                    if (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
+                    else        { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
+                } else {
+                    hf[hb][t] = u32x4{__float_as_uint(h0), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+                }
+            }
+        }
+        // phase B: y^T += W2c h^T
+#pragma unroll
+        for (int kg = 0; kg < HG; ++kg) {
+#pragma unroll
+            for (int nb = 0; nb < NBH; ++nb) {
+                const int row = nb * 16 + idx;
+                const u32x4 wf = *reinterpret_cast<const u32x4*>(lds2 + row * ROW2 + (swz<ROW2>(row, kg * 4 + g) << 4));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) P::mma(yacc[nb][t], wf, hf[kg][t]);
+            }
+        }
+        __syncthreads();
+        if (more) store_tiles(r1, r2);
+        __syncthreads();
+    }
+
+    resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
+}
+
+// ---------------------------------------------------------------------------
+// Attention for one (window, head, query tile).  Transposed orientation:
+//   S^T[key][q] = K q^T   (A = K rows from LDS,   B = Q rows in registers)
+//   O^T[d][q]  += V^T P^T (A = V^T rows from LDS, B = P^T = exp(S^T - m))
+// The S^T accumulator (4 consecutive keys per lane for one query) is, after
+// exponentiation and packing, directly the B fragment of the PV MFMA; the
+// matching key order of V^T is produced by the QKV epilogue.  Row max/sum
+// over keys = per-lane partials + shuffles over the 4 lane groups.
+// ---------------------------------------------------------------------------
+template <class P, int NTQ, int DH>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWK = DH * P::kBytes;            // K tile row bytes
+    constexpr int DG = ROWK / 64;                   // K-groups over head dim
+    constexpr int KT = 16384 / ROWK;                // keys per tile
+    constexpr int KB = KT / 16;                     // key 16-blocks per tile
+    constexpr int ROWV = KT * P::kBytes;            // V^T tile row bytes (128 or 64)
+    constexpr int PG = ROWV / 64;                   // K-groups of PV per tile
+    constexpr int DB = DH / 16;                     // head-dim 16-blocks
+    constexpr int SK = ROWK / 16;
+    constexpr int SV = ROWV / 16;
+    constexpr int WRK = 16384 / 16 / 256;           // 4
+    constexpr int WRV = (DH * ROWV) / 16 / 256;     // 4
+    char* ldsk = smem;
+    char* ldsv = smem + 16384;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15;
+    const int g = lane >> 4;
+    const AttnItem item = a.items[blockIdx.x];
+    const PpgWindow w = a.win[item.window];
+    const int head = blockIdx.y;
+    const int qw0 = item.q0 + wave * 16 * NTQ;      // first query of this wave
+
+    // Q fragments
+    u32x4 qf[DG][NTQ];
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        const int tq = qw0 + 16 * t + idx;
+        const int m = w.tok_off + tq;
+        const bool ok = (qw0 + 16 * t) < ((w.frames + 15) & ~15);   // inside the window's padded rows
+#pragma unroll
+        for (int kg = 0; kg < DG; ++kg) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(a.qk + (size_t)m * a.qk_ld_bytes + (size_t)head * ROWK + kg * 64 + g * 16);
+            qf[kg][t] = v;
+        }
+    }
+
+    int kend = w.valid;                              // keys >= valid are masked
+    if (a.causal) kend = min(kend, item.q0 + 64 * NTQ);
+    const int ntiles = (kend + KT - 1) / KT;
+
+    const char* kbase = a.qk + (size_t)w.tok_off * a.qk_ld_bytes + ((size_t)a.H + (size_t)head * DH) * P::kBytes;
+    const char* vbase = a.vt + (size_t)head * DH * a.vt_ld_bytes + (size_t)w.vt_off * P::kBytes;
+
+    auto load_tiles = [&](int kt, u32x4 (&rk)[WRK], u32x4 (&rv)[WRV]) {
+#pragma unroll
+        for (int i = 0; i < WRK; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / SK, p = slot % SK;
+            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(kt * KT + row) * a.qk_ld_bytes + p * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WRV; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / SV, p = slot % SV;
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)row * a.vt_ld_bytes + (size_t)kt * ROWV + p * 16);
+        }
+    };
+    auto store_tiles = [&](const u32x4 (&rk)[WRK], const u32x4 (&rv)[WRV]) {
+#pragma unroll
+        for (int i = 0; i < WRK; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / SK, p = slot % SK;
+            *reinterpret_cast<u32x4*>(ldsk + row * ROWK + (swz<ROWK>(row, p) << 4)) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WRV; ++i) {
+            const int slot = i * 256 + tid;
+            const int row = slot / SV, p = slot % SV;
+            *reinterpret_cast<u32x4*>(ldsv + row * ROWV + (swz<ROWV>(row, p) << 4)) = rv[i];
+        }
+    };
+
+    f32x4 oacc[DB][NTQ];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) oacc[db][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[NTQ], lrun[NTQ];
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) { mrun[t] = -INFINITY; lrun[t] = 0.f; }
+
+    u32x4 rk[WRK], rv[WRV];
+    if (ntiles > 0) {
+        load_tiles(0, rk, rv);
+        store_tiles(rk, rv);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const bool more = kt + 1 < ntiles;
+        if (more) load_tiles(kt + 1, rk, rv);
+
+        f32x4 sacc[KB][NTQ];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) sacc[kb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < DG; ++kg) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int row = kb * 16 + idx;
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(ldsk + row * ROWK + (swz<ROWK>(row, kg * 4 + g) << 4));
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) P::mma(sacc[kb][t], kf, qf[kg][t]);
+            }
+        }
+
+        u32x4 pf[PG][NTQ];
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const int tq = qw0 + 16 * t + idx;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * KT + kb * 16 + 4 * g + r;
+                    const bool masked = key >= w.valid || (a.causal && key > tq);
+                    const float s = masked ? -INFINITY : sacc[kb][t][r] * a.scale_log2e;
+                    sacc[kb][t][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = wave_max_g(mx);
+            const float mnew = fmaxf(mrun[t], mx);
+            const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+            const float alpha = exp2f(mrun[t] - msafe);
+            mrun[t] = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const float p0 = exp2f(sacc[kb][t][0] - msafe);
+                const float p1 = exp2f(sacc[kb][t][1] - msafe);
+                const float p2 = exp2f(sacc[kb][t][2] - msafe);
+                const float p3 = exp2f(sacc[kb][t][3] - msafe);
+                psum += (p0 + p1) + (p2 + p3);
+                if constexpr (P::kIsBF16) {
+                    if (kb & 1) { pf[kb >> 1][t].z = pack_bf16x2(p0, p1); pf[kb >> 1][t].w = pack_bf16x2(p2, p3); }
+                    else        { pf[kb >> 1][t].x = pack_bf16x2(p0, p1); pf[kb >> 1][t].y = pack_bf16x2(p2, p3); }
+                } else {
+                    pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
+                }
+            }
+            lrun[t] = lrun[t] * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
+                oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < PG; ++kg) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int row = db * 16 + idx;
+                const u32x4 vf = *reinterpret_cast<const u32x4*>(ldsv + row * ROWV + (swz<ROWV>(row, kg * 4 + g) << 4));
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) P::mma(oacc[db][t], vf, pf[kg][t]);
+            }
+        }
+        __syncthreads();
+        if (more) store_tiles(rk, rv);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        if ((qw0 + 16 * t) >= ((w.frames + 15) & ~15)) continue;
+        const int m = w.tok_off + qw0 + 16 * t + idx;
+        const float l = wave_sum_g(lrun[t]);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const int n = head * DH + db * 16 + 4 * g;
+            store4<P>(a.ao + ((size_t)m * a.H + n) * P::kBytes,
+                      oacc[db][t][0] * inv, oacc[db][t][1] * inv,
+                      oacc[db][t][2] * inv, oacc[db][t][3] * inv);
+        }
+    }
+}
+
+template <class P, int NT, int NB, int EPI>
+hipError_t launch_linear_t(const LinearArgs& a, int ypasses, hipStream_t s) {
+    const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
+    const size_t lds = 2 * NB * 16 * 128;
+    auto kern = linear_kernel<P, NT, NB, EPI>;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks, ypasses), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <class P>
+hipError_t launch_linear_p(int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s) {
+    switch (epi) {
+    case EPI_INCONV: return launch_linear_t<P, 2, 16, EPI_INCONV>(a, ypasses, s);
+    case EPI_QKV:    return launch_linear_t<P, 2, 16, EPI_QKV>(a, ypasses, s);
+    case EPI_RELU:   return launch_linear_t<P, 2, 16, EPI_RELU>(a, ypasses, s);
+    case EPI_OUTCONV:return launch_linear_t<P, 2, 3, EPI_OUTCONV>(a, ypasses, s);
+    case EPI_RESLN:
+        if (nb == 16) return launch_linear_t<P, 2, 16, EPI_RESLN>(a, ypasses, s);
+        if (nb == 32) return launch_linear_t<P, 1, 32, EPI_RESLN>(a, ypasses, s);
+        return hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+
+template <class P, int NT, int NBH>
+hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
+    const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
+    auto kern = ffn_kernel<P, NT, NBH>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 65536, s, a);
+    return hipGetLastError();
+}
+
+template <class P>
+hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
+    if (a.H == 256) {
+        if (nt == 1) return launch_ffn_t<P, 1, 16>(a, s);
+        if (nt == 3) return launch_ffn_t<P, 3, 16>(a, s);
+        return launch_ffn_t<P, 2, 16>(a, s);
+    }
+    if (a.H == 512) return launch_ffn_t<P, 1, 32>(a, s);
+    return hipErrorInvalidValue;
+}
+
+template <class P>
+hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
+    if (head_dim == 128) {
+        hipLaunchKernelGGL((attn_kernel<P, 2, 128>), dim3(nitems, heads), dim3(256), 32768, s, a);
+    } else if (head_dim == 256) {
+        hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems, heads), dim3(256), 32768, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+namespace ppg {
+
+int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }
+
+hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s) {
+    dim3 grid((a.M + 63) / 64, (a.Cp + 31) / 32);
+    if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(gather_kernel<PrecBF16>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gather_kernel<PrecF32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear(int precision, int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s) {
+    if (precision == PPG_PRECISION_BF16) return launch_linear_p<PrecBF16>(epi, nb, a, ypasses, s);
+    return launch_linear_p<PrecF32>(epi, nb, a, ypasses, s);
+}
+
+hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s) {
+    if (precision == PPG_PRECISION_BF16) return launch_ffn_p<PrecBF16>(a, nt, s);
+    return launch_ffn_p<PrecF32>(a, nt, s);
+}
+
+hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
+    if (precision == PPG_PRECISION_BF16) return launch_attn_p<PrecBF16>(a, nitems, heads, head_dim, s);
+    return launch_attn_p<PrecF32>(a, nitems, heads, head_dim, s);
+}
+
+}  // namespace ppg

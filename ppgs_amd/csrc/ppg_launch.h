@@ -1,0 +1,31 @@
+// Host-callable launchers implemented in ppg_kernels.hip / ppg_frontend.hip.
+#pragma once
+
+#include <algorithm>
+#include <hip/hip_runtime.h>
+
+#include "ppg_device.h"
+
+namespace ppg {
+
+int attn_query_tile(int head_dim);   // queries per attention workgroup
+
+hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s);
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+hipError_t launch_linear(int precision, int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s);
+hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
+hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
+
+struct FrontendTables {
+    const float* hann;        // [1024]
+    const float2* twiddle;    // [768] exp(-2 pi i j / 1024)
+    const int* mel_start;     // [80] first bin of each filter
+    const int* mel_count;     // [80]
+    const int* mel_offset;    // [80] offset into mel_weight
+    const float* mel_weight;  // packed non-zeros
+};
+
+hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int batch, int samples,
+                           void* spec, void* mel, hipStream_t s);
+
+}  // namespace ppg

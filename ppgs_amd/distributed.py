@@ -1,0 +1,127 @@
+"""Utterance-sharded multi-GPU inference: one process per GPU.
+
+The path shards by utterance with no data-path collective (utterances, and
+even their windows, are independent; weights are replicated).  The only
+exchange is the final gather of results to rank 0 over
+``torch.distributed`` (backend 'nccl' = RCCL over xGMI on the GPU box,
+'gloo' in the CPU tests): one all_gather of per-rank frame counts, then one
+padded all_gather of the (sum frames, 40) payload.  Not present in the
+reference, which is single-device.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import config, data
+
+
+def shard_lpt(costs, world_size):
+    """Longest-processing-time-first assignment: list of index lists, one per
+    rank; deterministic (ties broken by index)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for index in order:
+        rank = min(range(world_size), key=lambda r: (loads[r], r))
+        shards[rank].append(index)
+        loads[rank] += costs[index]
+    return shards
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment
+    and bind this rank to its GPU.  Returns (rank, world_size)."""
+    world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world_size > 1 and not dist.is_initialized():
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
+    return rank, world_size
+
+
+def gather_ragged(local, frame_counts_local, dst=0):
+    """Gather per-rank packed results to rank `dst`.
+
+    local: (frames_local, C) tensor holding this rank's utterances
+    back-to-back (frame-major); frame_counts_local: list of their lengths.
+    Returns on rank dst a list (one per rank) of lists of (C, frames)
+    tensors, None elsewhere.  Two collectives in total.
+    """
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if world_size == 1:
+        return [_split(local, frame_counts_local)]
+    rank = dist.get_rank()
+    device = local.device
+    counts = [None] * world_size
+    dist.all_gather_object(counts, [int(c) for c in frame_counts_local])
+    totals = [sum(c) for c in counts]
+    longest = max(max(totals), 1)
+    padded = torch.zeros((longest, local.shape[1]), dtype=local.dtype, device=device)
+    padded[:local.shape[0]] = local
+    buffers = [torch.empty_like(padded) for _ in range(world_size)]
+    dist.all_gather(buffers, padded)
+    if rank != dst:
+        return None
+    return [_split(buffers[r][:totals[r]], counts[r]) for r in range(world_size)]
+
+
+def _split(packed, counts):
+    out, offset = [], 0
+    for count in counts:
+        out.append(packed[offset:offset + count].T.contiguous())
+        offset += count
+    return out
+
+
+def from_audios_sharded(audios, compute=None, gpu=None, max_frames=32000,
+                        checkpoint=None, representation=config.REPRESENTATION):
+    """PPGs of a list of (1, samples) utterances using every rank.
+
+    Every rank passes the same list; rank r computes the utterances LPT
+    assigns to it (cost = algorithmic FLOPs of the chunked forward), packed
+    into padded batches under `max_frames`; results are gathered to rank 0,
+    which returns a list of (40, frames) tensors in input order (other ranks
+    return None).  `compute(padded_audio, sample_lengths) -> (B, 40, T)` is
+    the per-batch forward; by default the HIP engine.
+    """
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    frames = [a.shape[-1] // config.HOPSIZE for a in audios]
+    shards = shard_lpt([data.flops(f) for f in frames], world_size)
+    mine = shards[rank]
+    if compute is None:
+        from . import core, preprocess
+
+        def compute(padded, lengths):
+            features = preprocess.mel.from_audios(padded, lengths, gpu=gpu)
+            return core.from_features(
+                features, lengths // config.HOPSIZE,
+                representation=representation, checkpoint=checkpoint, gpu=gpu)
+    results = {}
+    for batch in data.pack_batches([frames[i] for i in mine], max_frames):
+        indices = [mine[j] for j in batch]
+        padded, lengths = data.collate([audios[i][:1] for i in indices])
+        out = compute(padded, lengths)
+        for row, index in enumerate(indices):
+            results[index] = out[row, :, :frames[index]]
+    channels = config.OUTPUT_CHANNELS
+    if mine:
+        local = torch.cat([results[i].T for i in mine], dim=0)
+    else:
+        device = 'cuda' if (torch.cuda.is_available() and (
+            not dist.is_initialized() or dist.get_backend() == 'nccl')) else 'cpu'
+        local = torch.zeros((0, channels), device=device)
+    gathered = gather_ragged(local.contiguous(), [frames[i] for i in mine])
+    if gathered is None:
+        return None
+    ordered = [None] * len(audios)
+    for r, shard in enumerate(shards):
+        for index, ppg in zip(shard, gathered[r]):
+            ordered[index] = ppg
+    return ordered

@@ -1,0 +1,320 @@
+"""ctypes binding of the C ABI in include/ppgs_amd.h (libppgs_amd.so).
+
+PyTorch-ROCm supplies device memory (tensors), the current HIP stream and the
+device index; all arithmetic happens in the HIP library.  There is no CPU or
+eager-PyTorch fallback: if the library is missing or no GPU is visible the
+calls raise.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import config, weights
+
+PPG_MAX_LAYERS = 16
+PRECISIONS = {'fp32': 0, 'bf16': 1}
+KERNEL_CLASSES = (
+    'gather', 'inconv', 'qkv', 'attention', 'outproj_ln', 'ffn',
+    'outconv_softmax', 'frontend')
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                         'libppgs_amd.so')
+_lib = None
+_lib_lock = threading.Lock()
+
+_FP = ctypes.POINTER(ctypes.c_float)
+
+
+class PpgConfig(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        'input_channels', 'hidden_channels', 'num_layers', 'ffn_channels',
+        'output_channels', 'kernel_size', 'heads', 'is_causal',
+        'max_positions', 'chunk_length', 'chunk_overlap', 'precision')]
+
+
+class PpgWeights(ctypes.Structure):
+    _fields_ = (
+        [('position_encoding', _FP), ('input_weight', _FP), ('input_bias', _FP)] +
+        [(name, _FP * PPG_MAX_LAYERS) for name in (
+            'in_proj_weight', 'in_proj_bias', 'out_proj_weight',
+            'out_proj_bias', 'linear1_weight', 'linear1_bias',
+            'linear2_weight', 'linear2_bias', 'norm1_weight', 'norm1_bias',
+            'norm2_weight', 'norm2_bias')] +
+        [('output_weight', _FP), ('output_bias', _FP)])
+
+
+class PpgWindow(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        'item', 'chunked', 'start', 'frames', 'valid', 'keep_lo', 'keep_hi',
+        'out_frame', 'tok_off', 'vt_off', 'pad0', 'pad1')]
+
+
+class PpgPlanInfo(ctypes.Structure):
+    _fields_ = [
+        ('num_windows', ctypes.c_int32), ('skipped_windows', ctypes.c_int32),
+        ('tokens', ctypes.c_int32), ('vt_tokens', ctypes.c_int32),
+        ('processed_frames', ctypes.c_int64),
+        ('attention_pairs', ctypes.c_int64),
+        ('workspace_bytes', ctypes.c_size_t)]
+
+
+# every symbol include/ppgs_amd.h declares: name -> (restype, argtypes)
+_I64P = ctypes.POINTER(ctypes.c_int64)
+SYMBOLS = {
+    'ppg_last_error': (ctypes.c_char_p, []),
+    'ppg_abi_version': (ctypes.c_int, []),
+    'ppg_engine_create': (ctypes.c_int, [
+        ctypes.POINTER(PpgConfig), ctypes.POINTER(PpgWeights), ctypes.c_int,
+        ctypes.POINTER(ctypes.c_void_p)]),
+    'ppg_engine_destroy': (None, [ctypes.c_void_p]),
+    'ppg_plan_windows': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _I64P, ctypes.c_int,
+        ctypes.POINTER(PpgWindow), ctypes.c_int, ctypes.POINTER(PpgPlanInfo)]),
+    'ppg_workspace_bytes': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _I64P, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_size_t)]),
+    'ppg_encode': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, _I64P, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'ppg_frontend': (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_engine_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'ppg_engine_profile_read': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+        _I64P]),
+    'ppg_engine_profile_reset': (ctypes.c_int, [ctypes.c_void_p]),
+    'ppg_frontend_profile': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    'ppg_frontend_profile_read': (ctypes.c_int, [
+        ctypes.c_int, ctypes.POINTER(ctypes.c_double), _I64P]),
+}
+
+
+def library():
+    """Load libppgs_amd.so (built in-tree by __graft_entry__.build / make)."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise RuntimeError(
+                    f'{_LIB_PATH} is missing: build it with '
+                    '`python -c "import __graft_entry__ as g; g.build()"` or '
+                    '`make -C ppgs_amd/csrc`. The PPG engine has no fallback '
+                    'path.')
+            lib = ctypes.CDLL(_LIB_PATH)
+            for name, (restype, argtypes) in SYMBOLS.items():
+                fn = getattr(lib, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+class PpgError(RuntimeError):
+    pass
+
+
+_ERRORS = {-1: ValueError, -2: PpgError, -3: PpgError, -4: ValueError}
+
+
+def _check(code):
+    if code < 0:
+        message = library().ppg_last_error().decode()
+        raise _ERRORS.get(code, PpgError)(f'ppgs_amd: {message} (code {code})')
+    return code
+
+
+def _lengths_array(lengths, batch):
+    if isinstance(lengths, torch.Tensor):
+        lengths = lengths.detach().cpu().reshape(-1).tolist()
+    elif isinstance(lengths, int):
+        lengths = [lengths]
+    lengths = [int(v) for v in lengths]
+    if len(lengths) != batch:
+        raise ValueError(
+            f'lengths has {len(lengths)} entries for a batch of {batch}')
+    return (ctypes.c_int64 * batch)(*lengths)
+
+
+def plan_windows(batch, frames, lengths, legacy_mode=False, engine=None):
+    """Host-only chunk plan (works without a GPU): (windows, info)."""
+    lib = library()
+    arr = _lengths_array(lengths, batch)
+    info = PpgPlanInfo()
+    handle = engine._handle if engine is not None else None
+    count = _check(lib.ppg_plan_windows(
+        handle, batch, frames, arr, int(legacy_mode), None, 0,
+        ctypes.byref(info)))
+    windows = (PpgWindow * max(count, 1))()
+    _check(lib.ppg_plan_windows(
+        handle, batch, frames, arr, int(legacy_mode), windows, count,
+        ctypes.byref(info)))
+    return list(windows)[:count], info
+
+
+class Engine:
+    """One loaded PPG network on one GPU (mirrors the per-model cache of
+    reference ppgs.infer, ppgs/core.py:565-583)."""
+
+    def __init__(self, state, device=0, precision='bf16', is_causal=False,
+                 heads=config.ATTENTION_HEADS):
+        if not torch.cuda.is_available():
+            raise PpgError(
+                'ppgs_amd: no HIP device visible; the engine has no CPU path')
+        lib = library()
+        cin, hidden, layers = weights.geometry(state)
+        self.input_channels = cin
+        self.hidden_channels = hidden
+        self.output_channels = state['output_layer.weight'].shape[0]
+        self.precision = precision
+        self.device = torch.device('cuda', device)
+        cfg = PpgConfig(
+            input_channels=cin, hidden_channels=hidden, num_layers=layers,
+            ffn_channels=(
+                state['model.layers.0.linear1.weight'].shape[0]
+                if layers else config.FFN_CHANNELS),
+            output_channels=self.output_channels,
+            kernel_size=state['input_layer.weight'].shape[2], heads=heads,
+            is_causal=int(is_causal),
+            max_positions=state['position.encoding'].shape[0],
+            chunk_length=config.CHUNK_LENGTH,
+            chunk_overlap=config.CHUNK_OVERLAP,
+            precision=PRECISIONS[precision])
+        keep = []
+
+        def ptr(key):
+            tensor = state[key].detach().to('cpu', torch.float32).contiguous()
+            keep.append(tensor)
+            return ctypes.cast(tensor.data_ptr(), _FP)
+        wts = PpgWeights()
+        wts.position_encoding = ptr('position.encoding')
+        wts.input_weight = ptr('input_layer.weight')
+        wts.input_bias = ptr('input_layer.bias')
+        wts.output_weight = ptr('output_layer.weight')
+        wts.output_bias = ptr('output_layer.bias')
+        names = {
+            'in_proj_weight': 'self_attn.in_proj_weight',
+            'in_proj_bias': 'self_attn.in_proj_bias',
+            'out_proj_weight': 'self_attn.out_proj.weight',
+            'out_proj_bias': 'self_attn.out_proj.bias',
+            'linear1_weight': 'linear1.weight', 'linear1_bias': 'linear1.bias',
+            'linear2_weight': 'linear2.weight', 'linear2_bias': 'linear2.bias',
+            'norm1_weight': 'norm1.weight', 'norm1_bias': 'norm1.bias',
+            'norm2_weight': 'norm2.weight', 'norm2_bias': 'norm2.bias'}
+        for field, key in names.items():
+            array = getattr(wts, field)
+            for l in range(layers):
+                array[l] = ptr(f'model.layers.{l}.{key}')
+        handle = ctypes.c_void_p()
+        _check(lib.ppg_engine_create(
+            ctypes.byref(cfg), ctypes.byref(wts), device, ctypes.byref(handle)))
+        self._handle = handle
+        self._lib = lib
+        self._workspace = None
+
+    def __del__(self):
+        handle = getattr(self, '_handle', None)
+        if handle:
+            self._lib.ppg_engine_destroy(handle)
+            self._handle = None
+
+    def workspace_bytes(self, batch, frames, lengths, legacy_mode=False):
+        size = ctypes.c_size_t()
+        _check(self._lib.ppg_workspace_bytes(
+            self._handle, batch, frames, _lengths_array(lengths, batch),
+            int(legacy_mode), ctypes.byref(size)))
+        return size.value
+
+    def encode(self, features, lengths, softmax=True, legacy_mode=False):
+        """features (B, Cin, T) fp16/fp32 on this engine's GPU -> (B, 40, T)
+        fp32 on the same GPU (posteriors, or logits if softmax=False)."""
+        if features.dim() != 3 or features.shape[1] != self.input_channels:
+            raise ValueError(
+                f'features must be (batch, {self.input_channels}, frames), '
+                f'got {tuple(features.shape)}')
+        features = features.to(self.device)
+        if features.dtype == torch.float16:
+            dtype = 0
+        else:
+            features = features.to(torch.float32)
+            dtype = 1
+        features = features.contiguous()
+        batch, _, frames = features.shape
+        arr = _lengths_array(lengths, batch)
+        size = ctypes.c_size_t()
+        _check(self._lib.ppg_workspace_bytes(
+            self._handle, batch, frames, arr, int(legacy_mode),
+            ctypes.byref(size)))
+        if self._workspace is None or self._workspace.numel() < size.value:
+            self._workspace = torch.empty(
+                max(size.value, 256), dtype=torch.uint8, device=self.device)
+        out = torch.empty(
+            (batch, self.output_channels, frames), dtype=torch.float32,
+            device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(self._lib.ppg_encode(
+                self._handle, features.data_ptr(), dtype, arr, batch, frames,
+                int(softmax), int(legacy_mode), out.data_ptr(),
+                self._workspace.data_ptr(), self._workspace.numel(), stream))
+        return out
+
+    # -- per-kernel HIP-event timing (bench.py roofline leg) ----------------
+    def profile(self, enable=True):
+        _check(self._lib.ppg_engine_profile(self._handle, int(enable)))
+        _check(self._lib.ppg_engine_profile_reset(self._handle))
+
+    def profile_read(self):
+        """{kernel class: (total ms, launches)} since profile(True)."""
+        result = {}
+        for index, name in enumerate(KERNEL_CLASSES[:-1]):
+            total, count = ctypes.c_double(), ctypes.c_int64()
+            _check(self._lib.ppg_engine_profile_read(
+                self._handle, index, ctypes.byref(total), ctypes.byref(count)))
+            result[name] = (total.value, count.value)
+        return result
+
+
+def frontend(audio, spectrogram=False, mel=True):
+    """audio (B, 1, N) or (B, N) fp32 on a GPU -> fp16 spectrogram (B,513,T)
+    and/or log-mel (B,80,T) on the same GPU, T = N // 160."""
+    if not audio.is_cuda:
+        raise PpgError('ppgs_amd: frontend input must live on a HIP device')
+    if audio.dim() == 3:
+        if audio.shape[1] != 1:
+            raise ValueError(f'audio must be (batch, 1, samples), got {tuple(audio.shape)}')
+        audio = audio[:, 0]
+    audio = audio.to(torch.float32).contiguous()
+    batch, samples = audio.shape
+    frames = samples // config.HOPSIZE
+    spec_out = mel_out = None
+    if spectrogram:
+        spec_out = torch.empty(
+            (batch, config.NUM_BINS, frames), dtype=torch.float16,
+            device=audio.device)
+    if mel:
+        mel_out = torch.empty(
+            (batch, config.NUM_MELS, frames), dtype=torch.float16,
+            device=audio.device)
+    lib = library()
+    with torch.cuda.device(audio.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _check(lib.ppg_frontend(
+            audio.device.index, audio.data_ptr(), batch, samples,
+            spec_out.data_ptr() if spectrogram else None,
+            mel_out.data_ptr() if mel else None, stream))
+    return spec_out, mel_out
+
+
+def frontend_profile(device, enable=True):
+    _check(library().ppg_frontend_profile(device, int(enable)))
+
+
+def frontend_profile_read(device):
+    total, count = ctypes.c_double(), ctypes.c_int64()
+    _check(library().ppg_frontend_profile_read(
+        device, ctypes.byref(total), ctypes.byref(count)))
+    return total.value, count.value

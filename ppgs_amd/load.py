@@ -1,0 +1,109 @@
+"""Checkpoint and audio loading (mirrors reference ppgs/load.py:17-81)."""
+import os
+import wave
+
+import numpy as np
+import torch
+
+from . import config, weights
+
+# Set to a path to use a local checkpoint when none is given
+# (reference ppgs/config/defaults.py:124)
+LOCAL_CHECKPOINT = os.environ.get('PPGS_AMD_CHECKPOINT')
+
+_HUB_REPO = 'CameronChurchwell/ppgs'
+_HUB_FILES = {'mel': 'mel-800k.pt', 'w2v2fb': 'w2v2fb-425k.pt'}
+
+
+def audio(file):
+    """Load an audio file as (1, samples) fp32 at 16 kHz.
+
+    The reference goes through torchaudio.load + Resample
+    (ppgs/load.py:17-30); here PCM/float WAV is decoded directly and other
+    sample rates are converted by :func:`ppgs_amd.core.resample`.
+    """
+    from . import core
+    from scipy.io import wavfile
+    sample_rate, data = wavfile.read(os.fspath(file))
+    if data.dtype == np.uint8:
+        samples = (data.astype(np.float32) - 128.) / 128.
+    elif np.issubdtype(data.dtype, np.integer):
+        samples = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+    else:
+        samples = data.astype(np.float32)
+    samples = torch.from_numpy(np.ascontiguousarray(samples))
+    if samples.dim() == 1:
+        samples = samples[None]
+    else:
+        samples = samples.T.contiguous()       # (channels, samples)
+    return core.resample(samples, sample_rate)
+
+
+def info(file):
+    """(num_samples, sample_rate) without decoding (reference uses
+    torchaudio.info, ppgs/data/dataset.py:187)."""
+    with wave.open(os.fspath(file), 'rb') as handle:
+        return handle.getnframes(), handle.getframerate()
+
+
+def state_dict(checkpoint=None, representation=None):
+    """The model parameters as a reference-layout state dict.
+
+    Resolution order follows reference ppgs/load.py:33-81: explicit
+    ``checkpoint`` (a ``.pt`` path holding either a bare state_dict or
+    ``{'model': state_dict}``; a dict is accepted as-is), else
+    ``LOCAL_CHECKPOINT``, else the HF-hub file of the representation.
+    """
+    if representation not in (None, 'mel', 'w2v2fb'):
+        raise ValueError(
+            'Supplying representation directly only supported '
+            'for w2v2fb and mel')
+    if isinstance(checkpoint, dict):
+        state = checkpoint
+    else:
+        if checkpoint is None:
+            checkpoint = LOCAL_CHECKPOINT
+        if checkpoint is None:
+            import huggingface_hub
+            name = _HUB_FILES.get(representation or config.REPRESENTATION)
+            if name is None:
+                raise ValueError(
+                    f'No default checkpoints exist for '
+                    f'representation {representation}')
+            checkpoint = huggingface_hub.hf_hub_download(_HUB_REPO, name)
+        state = torch.load(checkpoint, map_location='cpu', weights_only=True)
+    if 'model' in state and not torch.is_tensor(state['model']):
+        state = state['model']
+    expected = weights.state_dict_shapes(*_geometry_args(state))
+    for key, shape in expected.items():
+        if key not in state:
+            raise KeyError(f'checkpoint is missing {key}')
+        if tuple(state[key].shape) != tuple(shape):
+            raise ValueError(
+                f'checkpoint {key} has shape {tuple(state[key].shape)}, '
+                f'expected {tuple(shape)}')
+    if representation is not None:
+        want = config.MODEL_GEOMETRY[representation]
+        cin, hidden, _ = weights.geometry(state)
+        if (cin, hidden) != (want['input_channels'], want['hidden_channels']):
+            raise ValueError(
+                f'checkpoint geometry (Cin={cin}, H={hidden}) does not match '
+                f'representation {representation}')
+    return state
+
+
+def _geometry_args(state):
+    cin, hidden, layers = weights.geometry(state)
+    return (cin, hidden, layers, state['output_layer.weight'].shape[0],
+            state['input_layer.weight'].shape[2],
+            (state['model.layers.0.linear1.weight'].shape[0]
+             if layers else config.FFN_CHANNELS),
+            state['position.encoding'].shape[0])
+
+
+def model(checkpoint=None, representation=None, gpu=None, precision=None,
+          is_causal=None):
+    """Load a model onto a GPU -> :class:`ppgs_amd.engine.Engine`
+    (counterpart of reference ppgs.load.model, ppgs/load.py:33-81)."""
+    from . import core
+    return core.engine_for(representation, checkpoint, gpu, precision, is_causal)
