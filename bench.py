@@ -1,0 +1,188 @@
+"""Benchmark of the PPG hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one pass of the whole hot path over one batch of synthetic input
+that is already resident in HBM: mel frontend (STFT + mel + log) -> 5-layer
+transformer encoder with the reference's 500/50 chunking -> per-frame softmax,
+for BASELINE.json configs[1]: mel representation, batch = 32 x 1000 frames
+(32 x 160000 samples of 16 kHz audio), bf16 MFMA arithmetic.  Weights are a
+seeded random checkpoint of the reference architecture (no network).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): utterances are
+independent, so every rank runs its own 32 x 1000 batch (weak scaling, no
+data-path collective); value = frames of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused
+FFN): algorithmic FLOPs per launch / its mean launch duration measured with
+HIP events on the launch stream inside the timed region.  `cpu_baseline` is
+the CPU oracle (fp32 restatement of the reference path, proven equal to the
+reference modules by tests/test_oracle_golden.py) timed on the host cores on
+a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                                             # noqa: E402
+import torch.distributed as dist                         # noqa: E402
+
+BATCH = 32
+FRAMES = 1000
+SAMPLES = FRAMES * 160
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_FP32_TFLOPS = 157.3
+
+
+def parse():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=50)
+    parser.add_argument('--warmup', type=int, default=10)
+    parser.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    parser.add_argument('--cpu-seconds', type=float, default=12.0,
+                        help='budget of the CPU-baseline leg')
+    parser.add_argument('--no-cpu', action='store_true')
+    return parser.parse_args()
+
+
+def cpu_baseline(state, seconds):
+    """Oracle (CPU port of the reference path, fp32, autocast off) on a
+    bounded sample: batches of 4 x 160000 samples for about `seconds`."""
+    from oracle import ppg_oracle
+    generator = torch.Generator().manual_seed(1234)
+    audio = 0.1 * torch.randn(4, 1, SAMPLES, generator=generator)
+    ppg_oracle.from_audio(state, audio[:1, :, :16000])          # warm-up
+    start = time.perf_counter()
+    batches = 0
+    while True:
+        ppg_oracle.from_audio(state, audio)
+        batches += 1
+        elapsed = time.perf_counter() - start
+        if elapsed > seconds or batches >= 64:
+            break
+    return {
+        'value': batches * 4 * FRAMES / elapsed,
+        'unit': 'frames/s',
+        'cores': torch.get_num_threads(),
+        'kind': 'port',
+        'sample': f'{batches} batches of 4 x {FRAMES} frames '
+                  f'(mel frontend + encoder + softmax, fp32 CPU oracle), '
+                  f'{elapsed:.1f} s on {os.cpu_count()} logical cores',
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    import ppgs_amd
+    from ppgs_amd import data, engine as E
+
+    state = ppgs_amd.weights.seeded_state_dict(seed=1234)
+    model = E.Engine(state, local_rank, args.precision)
+    generator = torch.Generator().manual_seed(1234 + rank)
+    audio = (0.1 * torch.randn(BATCH, 1, SAMPLES, generator=generator)).cuda()
+    lengths = [FRAMES] * BATCH
+
+    def step():
+        mel = ppgs_amd.preprocess.mel.from_audios(audio)
+        return model.encode(mel, lengths)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    assert out.shape == (BATCH, 40, FRAMES) and bool(torch.isfinite(out).all())
+
+    model.profile(True)
+    E.frontend_profile(local_rank, True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - start
+    if world > 1:
+        worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        elapsed = float(worst.item())
+    kernels = model.profile_read()
+    kernels['frontend'] = E.frontend_profile_read(local_rank)
+    model.profile(False)
+    E.frontend_profile(local_rank, False)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        frames_per_s = world * BATCH * FRAMES * args.steps / elapsed
+        _, info = E.plan_windows(BATCH, FRAMES, lengths)
+        hidden, ffn = 256, 2048
+        ffn_ms, ffn_launches = kernels['ffn']
+        ffn_flops = 4.0 * hidden * ffn * info.processed_frames
+        ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_launches, 1)) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_FP32_TFLOPS
+        step_flops = BATCH * data.flops(FRAMES)
+        line = {
+            'metric': 'PPG frames/sec (whole node), mel repr, batch=32x1000 frames',
+            'value': frames_per_s,
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.precision,
+            'data': 'synthetic 16 kHz audio (0.1*randn, seed 1234), '
+                    'seeded random weights of the reference architecture',
+            'config': {
+                'workload': 'configs[1]: mel representation, batch=32 x 1000 '
+                            'frames per GPU, audio resident in HBM -> '
+                            '(32,40,1000) fp32 posteriors in HBM',
+                'batch': BATCH, 'frames': FRAMES, 'per_gpu_batches': 1,
+                'parallelism': f'utterance-sharded x{world}, no data-path collective',
+            },
+            'roofline': {
+                'kernel': 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)',
+                'bound': 'mfma',
+                'achieved': ffn_tflops,
+                'peak': peak,
+                'unit': 'TFLOP/s',
+                'frac': ffn_tflops / peak,
+                'traffic': None,
+                'flops_per_launch': ffn_flops,
+                'mean_launch_ms': ffn_ms / max(ffn_launches, 1),
+            },
+            'end_to_end_tflops': step_flops * args.steps / elapsed / 1e12,
+            'end_to_end_mfma_frac': step_flops * args.steps / elapsed / 1e12 / peak,
+            'kernel_ms_per_step': {
+                k: v[0] / args.steps for k, v in kernels.items()},
+        }
+        if world == 1 and not args.no_cpu:
+            line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
+            line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
