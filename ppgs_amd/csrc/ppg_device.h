@@ -42,8 +42,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
     return __uint_as_float(((uint32_t)h) << 16);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two fp32 -> packed bf16 (round to nearest even): one v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_rne(lo) | ((uint32_t)f32_to_bf16_rne(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
 struct PrecBF16 {

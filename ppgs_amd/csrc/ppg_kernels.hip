@@ -43,6 +43,112 @@ __device__ __forceinline__ int swz(int row, int p) {
     else return p ^ ((row >> 2) & 3);
 }
 
+
+// 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS address is the
+// wave-uniform base + lane*16, the global address is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Stage a [ROWS][ROW_BYTES] tile (global row stride gstride) into LDS by DMA.
+// LDS image: 16-byte slot (row, pp) holds global piece p = swz(row, pp); the
+// image is lane-linear per wave-instruction (1 KiB pieces), the swizzle is
+// applied on the SOURCE address and again (same involution) on the reads.
+template <int ROWS, int ROW_BYTES, int NWAVES>
+__device__ __forceinline__ void stage_tile(const char* gsrc, size_t gstride, char* lds, int wave, int lane) {
+    constexpr int S = ROW_BYTES / 16;
+    constexpr int PIECES = ROWS * S / 64;
+    static_assert((ROWS * S) % 64 == 0, "tile must be a whole number of 1 KiB pieces");
+#pragma unroll
+    for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
+        const int piece = i * NWAVES + wave;
+        if (PIECES % NWAVES == 0 || piece < PIECES) {
+            const int slot = piece * 64 + lane;
+            const int row = slot / S, pp = slot % S;
+            glds16(gsrc + (size_t)row * gstride + (swz<ROW_BYTES>(row, pp) << 4), lds + piece * 1024);
+        }
+    }
+}
+
+// All DMA of this wave landed + workgroup barrier.
+__device__ __forceinline__ void dma_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// LDS byte address (low 32 bits of the flat address of a __shared__ object)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// ds_read_b128 the compiler does not schedule or count: it sinks ordinary LDS
+// loads next to their first use and waits lgkmcnt(0) after every one or two
+// (a single wave per SIMD then pays the full LDS latency per MFMA pair), and
+// it drains in-flight LDS DMA (vmcnt(0)) before LDS loads it cannot prove
+// disjoint.  These asm reads are waited for by lgkm_wait<N>() below.
+template <int OFF>
+__device__ __forceinline__ void ds_read_b128_asm(u32x4& dst, uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// Wait until at most N LDS operations issued after `r`'s read are outstanding;
+// `r` is tied to the statement so that no consumer (or copy) of it can be
+// placed above the wait.
+template <int N>
+__device__ __forceinline__ void lgkm_wait(u32x4& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);   // register-only MFMAs stay below too
+}
+
+// Address of MFMA fragment i = (kg, blk) = (i / NBLK, i % NBLK) of a swizzled
+// [rows][ROW_BYTES] LDS tile (row = blk*16 + idx, 16-byte slot kg*4 + g XOR
+// the row swizzle), split into a lane-variable base -- one of VAR variants,
+// selected by the low bits of kg that the XOR mixes with lane bits -- and a
+// compile-time immediate for the ds_read offset field.
+template <int ROW_BYTES, int NBLK>
+struct FragLayout {
+    static constexpr int VAR = ROW_BYTES >= 256 ? 4 : (ROW_BYTES == 128 ? 2 : 1);
+    static constexpr int variant(int i) { return (i / NBLK) % VAR; }
+    static constexpr int imm(int i) { return (i % NBLK) * 16 * ROW_BYTES + ((i / NBLK) / VAR) * VAR * 64; }
+    static __device__ __forceinline__ uint32_t base(int idx, int g, int j) {
+        if constexpr (ROW_BYTES >= 256) return idx * ROW_BYTES + ((((j * 4) ^ (idx & 12)) + ((g ^ idx) & 3)) << 4);
+        else if constexpr (ROW_BYTES == 128) return idx * 128 + ((((j * 4) ^ (idx & 4)) + ((g ^ idx) & 3)) << 4);
+        else return idx * 64 + ((g ^ ((idx >> 2) & 3)) << 4);
+    }
+    static __device__ __forceinline__ void bases(uint32_t tile, int idx, int g, uint32_t (&fb)[VAR]) {
+#pragma unroll
+        for (int j = 0; j < VAR; ++j) fb[j] = tile + base(idx, g, j);
+    }
+};
+
+// Software-pipelined LDS fragment stream for one wave per SIMD: D reads are
+// kept in flight; fragment I is consumed (its MFMAs issued) and its ring slot
+// immediately re-armed with fragment I + D.
+template <class L, int I, int R, int D, class USE>
+__device__ __forceinline__ void lds_stream_step(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR], USE& use) {
+    if constexpr (I < R) {
+        lgkm_wait<(R - 1 - I < D - 1) ? (R - 1 - I) : (D - 1)>(ring[I % D]);
+        use(std::integral_constant<int, I>{}, ring[I % D]);
+        if constexpr (I + D < R) ds_read_b128_asm<L::imm(I + D)>(ring[I % D], fb[L::variant(I + D)]);
+        lds_stream_step<L, I + 1, R, D>(ring, fb, use);
+    }
+}
+template <class L, int I, int R, int D>
+__device__ __forceinline__ void lds_stream_prime(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR]) {
+    if constexpr (I < D && I < R) {
+        ds_read_b128_asm<L::imm(I)>(ring[I], fb[L::variant(I)]);
+        lds_stream_prime<L, I + 1, R, D>(ring, fb);
+    }
+}
+template <class L, int R, int D, class USE>
+__device__ __forceinline__ void lds_stream(const uint32_t (&fb)[L::VAR], USE use) {
+    u32x4 ring[D];
+    lds_stream_prime<L, 0, R, D>(ring, fb);
+    lds_stream_step<L, 0, R, D>(ring, fb, use);
+}
+
 // ---------------------------------------------------------------------------
 // LayerNorm(acc + bias + residual) epilogue, acc in the transposed C layout
 // (lane: token = tok0 + 16t + idx, features nb*16 + 4g + r).
@@ -172,8 +278,6 @@ template <class P, int NT, int NB, int EPI>
 __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = NB * 16 * 128;
-    constexpr int SLOTS = NB * 16 * 8;
-    constexpr int WR = (SLOTS + 255) / 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -192,25 +296,8 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
     const char* wbase = a.W + (size_t)n0 * a.total_groups * 64;
     const int w_row_bytes = a.total_groups * 64;
 
-    auto load_w = [&](int s, u32x4 (&wr)[WR]) {
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int slot = i * 256 + tid;
-            if (SLOTS % 256 == 0 || slot < SLOTS) {
-                const int row = slot >> 3, p = slot & 7;
-                wr[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)row * w_row_bytes + s * 128 + p * 16);
-            }
-        }
-    };
-    auto store_w = [&](char* buf, const u32x4 (&wr)[WR]) {
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int slot = i * 256 + tid;
-            if (SLOTS % 256 == 0 || slot < SLOTS) {
-                const int row = slot >> 3, p = slot & 7;
-                *reinterpret_cast<u32x4*>(buf + row * 128 + (swz<128>(row, p) << 4)) = wr[i];
-            }
-        }
+    auto stage_w = [&](int s_, char* buf) {
+        stage_tile<NB * 16, 128, 4>(wbase + (size_t)s_ * 128, (size_t)w_row_bytes, buf, wave, lane);
     };
     // activation fragments of tile s (K-groups 2s, 2s+1)
     auto load_act = [&](int s, u32x4 (&af)[2][NT]) {
@@ -239,12 +326,10 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
         for (int t = 0; t < NT; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int steps = a.total_groups >> 1;
-    u32x4 wr[WR];
     u32x4 acur[2][NT], anext[2][NT];
-    load_w(0, wr);
+    stage_w(0, smem);
     load_act(0, acur);
-    store_w(smem, wr);
-    __syncthreads();
+    dma_wait_barrier();
 
     // SWAP (V pass of the QKV projection) exchanges the MFMA operands so the
     // accumulator comes out token-major-transposed; compile-time per loop.
@@ -253,31 +338,31 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
         for (int s = 0; s < steps; ++s) {
             const bool more = s + 1 < steps;
             if (more) {
-                load_w(s + 1, wr);
+                stage_w(s + 1, smem + ((s + 1) & 1) * TILE_BYTES);
                 load_act(s + 1, anext);
             }
             const char* buf = smem + (s & 1) * TILE_BYTES;
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int row = nb * 16 + idx;
-                    const u32x4 wf = *reinterpret_cast<const u32x4*>(buf + row * 128 + (swz<128>(row, kg * 4 + g) << 4));
+            // fragment i = (kg, nb) = (i / NB, i % NB)
+            using L = FragLayout<128, NB>;
+            uint32_t fb[L::VAR];
+            L::bases(lds_addr(buf), idx, g, fb);
+            lds_stream<L, 2 * NB, (NB >= 8 ? 6 : 3)>(
+                fb,
+                [&](auto ic, const u32x4& wf) {
+                    constexpr int i = decltype(ic)::value;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        if constexpr (SWAP) P::mma(acc[nb][t], acur[kg][t], wf);
-                        else P::mma(acc[nb][t], wf, acur[kg][t]);
+                        if constexpr (SWAP) P::mma(acc[i % NB][t], acur[i / NB][t], wf);
+                        else P::mma(acc[i % NB][t], wf, acur[i / NB][t]);
                     }
-                }
-            }
+                });
             if (more) {
-                store_w(smem + ((s + 1) & 1) * TILE_BYTES, wr);
 #pragma unroll
                 for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acur[kg][t] = anext[kg][t];
             }
-            __syncthreads();
+            dma_wait_barrier();
         }
     };
     if constexpr (EPI == EPI_QKV) {
@@ -436,7 +521,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
 // W1/W2 chunk tiles (32 KiB each) are staged global->regs->LDS.
 // ---------------------------------------------------------------------------
 template <class P, int NT, int NBH>
-__global__ __launch_bounds__(256) void ffn_kernel(FfnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = NBH * 16;
     constexpr int ROW1 = H * P::kBytes;             // W1 tile row bytes
@@ -445,12 +530,8 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnArgs a) {
     constexpr int HB = HC / 16;                     // hidden 16-blocks per chunk
     constexpr int ROW2 = HC * P::kBytes;            // W2 tile row bytes (128 or 64)
     constexpr int HG = ROW2 / 64;                   // K-groups of phase B per chunk
-    constexpr int S1 = ROW1 / 16;                   // slots per W1 row
-    constexpr int S2 = ROW2 / 16;
-    constexpr int WR1 = 32768 / 16 / 256;           // 8
-    constexpr int WR2 = (H * ROW2) / 16 / 256;      // 8
-    char* lds1 = smem;
-    char* lds2 = smem + 32768;
+    // LDS: 2 x {W1 tile 32 KiB, W2 tile 32 KiB} (DMA double buffer) + b1
+    char* ldsb1 = smem + 131072;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -459,6 +540,14 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnArgs a) {
     const int g = lane >> 4;
     const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
     const int NC = a.F / HC;
+
+    auto stage = [&](int c, char* buf) {
+        stage_tile<HC, ROW1, 4>(a.W1 + (size_t)c * 32768, (size_t)ROW1, buf, wave, lane);
+        stage_tile<H, ROW2, 4>(a.W2p + (size_t)c * ROW2, (size_t)a.F * P::kBytes, buf + 32768, wave, lane);
+    };
+    stage(0, smem);
+    for (int i = tid; i < a.F / 4; i += 256)
+        reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
 
     const char* actp = P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X);
     u32x4 xf[XG][NT];
@@ -473,74 +562,55 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnArgs a) {
         }
     }
 
-    auto load_tiles = [&](int c, u32x4 (&r1)[WR1], u32x4 (&r2)[WR2]) {
-        const char* src1 = a.W1 + (size_t)c * 32768;                 // HC contiguous rows
-#pragma unroll
-        for (int i = 0; i < WR1; ++i) r1[i] = *reinterpret_cast<const u32x4*>(src1 + (size_t)(i * 256 + tid) * 16);
-#pragma unroll
-        for (int i = 0; i < WR2; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / S2, p = slot % S2;
-            r2[i] = *reinterpret_cast<const u32x4*>(a.W2p + ((size_t)row * a.F + (size_t)c * HC) * P::kBytes + p * 16);
-        }
-    };
-    auto store_tiles = [&](const u32x4 (&r1)[WR1], const u32x4 (&r2)[WR2]) {
-#pragma unroll
-        for (int i = 0; i < WR1; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / S1, p = slot % S1;
-            *reinterpret_cast<u32x4*>(lds1 + row * ROW1 + (swz<ROW1>(row, p) << 4)) = r1[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WR2; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / S2, p = slot % S2;
-            *reinterpret_cast<u32x4*>(lds2 + row * ROW2 + (swz<ROW2>(row, p) << 4)) = r2[i];
-        }
-    };
-
     f32x4 yacc[NBH][NT];
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
         for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 r1[WR1], r2[WR2];
-    load_tiles(0, r1, r2);
-    store_tiles(r1, r2);
-    __syncthreads();
+    dma_wait_barrier();
 
     for (int c = 0; c < NC; ++c) {
-        const bool more = c + 1 < NC;
-        if (more) load_tiles(c + 1, r1, r2);
+        const uint32_t lds1a = lds_addr(smem) + (c & 1) * 65536;
+        const uint32_t lds2a = lds1a + 32768;
+        // b1 of this chunk: read before the next chunk's DMA is issued (an
+        // ordinary LDS load behind an in-flight LDS DMA makes hipcc drain it)
+        u32x4 b1f[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+            ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (c * HC + hb * 16 + 4 * g) * 4);
+        if (c + 1 < NC) stage(c + 1, smem + ((c + 1) & 1) * 65536);
 
-        // phase A: h^T = W1c x^T
+        // phase A: h^T = W1c x^T ; fragment i = (kg, hb) = (i / HB, i % HB)
         f32x4 hacc[HB][NT];
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int t = 0; t < NT; ++t) hacc[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        using LA = FragLayout<ROW1, HB>;
+        uint32_t fba[LA::VAR];
+        LA::bases(lds1a, idx, g, fba);
+        lds_stream<LA, XG * HB, 6>(
+            fba,
+            [&](auto ic, const u32x4& wf) {
+                constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int kg = 0; kg < XG; ++kg) {
+                for (int t = 0; t < NT; ++t) P::mma(hacc[i % HB][t], wf, xf[i / HB][t]);
+            });
+        // bias + ReLU, pack as phase-B fragments (the stream's last wait was
+        // lgkmcnt(0): the older b1 reads have landed)
 #pragma unroll
-            for (int hb = 0; hb < HB; ++hb) {
-                const int row = hb * 16 + idx;
-                const u32x4 wf = *reinterpret_cast<const u32x4*>(lds1 + row * ROW1 + (swz<ROW1>(row, kg * 4 + g) << 4));
-#pragma unroll
-                for (int t = 0; t < NT; ++t) P::mma(hacc[hb][t], wf, xf[kg][t]);
-            }
-        }
-        // bias + ReLU, pack as phase-B fragments
+        for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
         u32x4 hf[HG][NT];
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb) {
-            const float4 bv = *reinterpret_cast<const float4*>(a.b1 + c * HC + hb * 16 + 4 * g);
+            const u32x4 bv = b1f[hb];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float h0 = fmaxf(hacc[hb][t][0] + bv.x, 0.f);
-                const float h1 = fmaxf(hacc[hb][t][1] + bv.y, 0.f);
-                const float h2 = fmaxf(hacc[hb][t][2] + bv.z, 0.f);
-                const float h3 = fmaxf(hacc[hb][t][3] + bv.w, 0.f);
+                const float h0 = fmaxf(hacc[hb][t][0] + __uint_as_float(bv.x), 0.f);
+                const float h1 = fmaxf(hacc[hb][t][1] + __uint_as_float(bv.y), 0.f);
+                const float h2 = fmaxf(hacc[hb][t][2] + __uint_as_float(bv.z), 0.f);
+                const float h3 = fmaxf(hacc[hb][t][3] + __uint_as_float(bv.w), 0.f);
                 if constexpr (P::kIsBF16) {
                     if (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
                     else        { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
@@ -549,20 +619,18 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnArgs a) {
                 }
             }
         }
-        // phase B: y^T += W2c h^T
+        // phase B: y^T += W2c h^T ; fragment i = (kg, nb) = (i / NBH, i % NBH)
+        using LB = FragLayout<ROW2, NBH>;
+        uint32_t fbb[LB::VAR];
+        LB::bases(lds2a, idx, g, fbb);
+        lds_stream<LB, HG * NBH, 6>(
+            fbb,
+            [&](auto ic, const u32x4& wf) {
+                constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int kg = 0; kg < HG; ++kg) {
-#pragma unroll
-            for (int nb = 0; nb < NBH; ++nb) {
-                const int row = nb * 16 + idx;
-                const u32x4 wf = *reinterpret_cast<const u32x4*>(lds2 + row * ROW2 + (swz<ROW2>(row, kg * 4 + g) << 4));
-#pragma unroll
-                for (int t = 0; t < NT; ++t) P::mma(yacc[nb][t], wf, hf[kg][t]);
-            }
-        }
-        __syncthreads();
-        if (more) store_tiles(r1, r2);
-        __syncthreads();
+                for (int t = 0; t < NT; ++t) P::mma(yacc[i % NBH][t], wf, hf[i / NBH][t]);
+            });
+        dma_wait_barrier();
     }
 
     resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
@@ -587,12 +655,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     constexpr int ROWV = KT * P::kBytes;            // V^T tile row bytes (128 or 64)
     constexpr int PG = ROWV / 64;                   // K-groups of PV per tile
     constexpr int DB = DH / 16;                     // head-dim 16-blocks
-    constexpr int SK = ROWK / 16;
-    constexpr int SV = ROWV / 16;
-    constexpr int WRK = 16384 / 16 / 256;           // 4
-    constexpr int WRV = (DH * ROWV) / 16 / 256;     // 4
-    char* ldsk = smem;
-    char* ldsv = smem + 16384;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -626,33 +688,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const char* kbase = a.qk + (size_t)w.tok_off * a.qk_ld_bytes + ((size_t)a.H + (size_t)head * DH) * P::kBytes;
     const char* vbase = a.vt + (size_t)head * DH * a.vt_ld_bytes + (size_t)w.vt_off * P::kBytes;
 
-    auto load_tiles = [&](int kt, u32x4 (&rk)[WRK], u32x4 (&rv)[WRV]) {
-#pragma unroll
-        for (int i = 0; i < WRK; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / SK, p = slot % SK;
-            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(kt * KT + row) * a.qk_ld_bytes + p * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < WRV; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / SV, p = slot % SV;
-            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)row * a.vt_ld_bytes + (size_t)kt * ROWV + p * 16);
-        }
-    };
-    auto store_tiles = [&](const u32x4 (&rk)[WRK], const u32x4 (&rv)[WRV]) {
-#pragma unroll
-        for (int i = 0; i < WRK; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / SK, p = slot % SK;
-            *reinterpret_cast<u32x4*>(ldsk + row * ROWK + (swz<ROWK>(row, p) << 4)) = rk[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WRV; ++i) {
-            const int slot = i * 256 + tid;
-            const int row = slot / SV, p = slot % SV;
-            *reinterpret_cast<u32x4*>(ldsv + row * ROWV + (swz<ROWV>(row, p) << 4)) = rv[i];
-        }
+    auto stage = [&](int kt, char* buf) {
+        stage_tile<KT, ROWK, 4>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, buf, wave, lane);
+        stage_tile<DH, ROWV, 4>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, buf + 16384, wave, lane);
     };
 
     f32x4 oacc[DB][NTQ];
@@ -664,32 +702,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) { mrun[t] = -INFINITY; lrun[t] = 0.f; }
 
-    u32x4 rk[WRK], rv[WRV];
-    if (ntiles > 0) {
-        load_tiles(0, rk, rv);
-        store_tiles(rk, rv);
-    }
-    __syncthreads();
+    if (ntiles > 0) stage(0, smem);
+    dma_wait_barrier();
 
     for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = kt + 1 < ntiles;
-        if (more) load_tiles(kt + 1, rk, rv);
+        const uint32_t ldsk = lds_addr(smem) + (kt & 1) * 32768;
+        const uint32_t ldsv = ldsk + 16384;
+        if (kt + 1 < ntiles) stage(kt + 1, smem + ((kt + 1) & 1) * 32768);
 
         f32x4 sacc[KB][NTQ];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int t = 0; t < NTQ; ++t) sacc[kb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // fragment i = (kg, kb) = (i / KB, i % KB)
+        using LK = FragLayout<ROWK, KB>;
+        uint32_t fbk[LK::VAR];
+        LK::bases(ldsk, idx, g, fbk);
+        lds_stream<LK, DG * KB, 6>(
+            fbk,
+            [&](auto ic, const u32x4& kf) {
+                constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int kg = 0; kg < DG; ++kg) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const int row = kb * 16 + idx;
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(ldsk + row * ROWK + (swz<ROWK>(row, kg * 4 + g) << 4));
-#pragma unroll
-                for (int t = 0; t < NTQ; ++t) P::mma(sacc[kb][t], kf, qf[kg][t]);
-            }
-        }
+                for (int t = 0; t < NTQ; ++t) P::mma(sacc[i % KB][t], kf, qf[i / KB][t]);
+            });
 
         u32x4 pf[PG][NTQ];
 #pragma unroll
@@ -733,19 +769,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
             }
         }
+        // fragment i = (kg, db) = (i / DB, i % DB)
+        using LV = FragLayout<ROWV, DB>;
+        uint32_t fbv[LV::VAR];
+        LV::bases(ldsv, idx, g, fbv);
+        lds_stream<LV, PG * DB, 6>(
+            fbv,
+            [&](auto ic, const u32x4& vf) {
+                constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int kg = 0; kg < PG; ++kg) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                const int row = db * 16 + idx;
-                const u32x4 vf = *reinterpret_cast<const u32x4*>(ldsv + row * ROWV + (swz<ROWV>(row, kg * 4 + g) << 4));
-#pragma unroll
-                for (int t = 0; t < NTQ; ++t) P::mma(oacc[db][t], vf, pf[kg][t]);
-            }
-        }
-        __syncthreads();
-        if (more) store_tiles(rk, rv);
-        __syncthreads();
+                for (int t = 0; t < NTQ; ++t) P::mma(oacc[i % DB][t], vf, pf[i / DB][t]);
+            });
+        dma_wait_barrier();
     }
 
 #pragma unroll
@@ -796,7 +831,10 @@ template <class P, int NT, int NBH>
 hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
     auto kern = ffn_kernel<P, NT, NBH>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 65536, s, a);
+    const size_t lds = 131072 + (size_t)a.F * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -814,9 +852,9 @@ hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
 template <class P>
 hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
     if (head_dim == 128) {
-        hipLaunchKernelGGL((attn_kernel<P, 2, 128>), dim3(nitems, heads), dim3(256), 32768, s, a);
+        hipLaunchKernelGGL((attn_kernel<P, 2, 128>), dim3(nitems, heads), dim3(256), 65536, s, a);
     } else if (head_dim == 256) {
-        hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems, heads), dim3(256), 32768, s, a);
+        hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems, heads), dim3(256), 65536, s, a);
     } else {
         return hipErrorInvalidValue;
     }
