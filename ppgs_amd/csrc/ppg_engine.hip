@@ -165,7 +165,8 @@ struct PpgEngine {
     int in_groups_per_tap = 0, in_total_groups = 0;
     int out_groups_per_tap = 0, out_total_groups = 0;
     int head_dim = 0;
-    int ffn_nt = 2;
+    int ffn_nt = 0;       // 0 = pick per launch (choose_nt); 1..3 = forced
+    int num_cus = 256;
     bool ffn_fused = true;
     std::vector<void*> allocs;
     float* pe = nullptr;
@@ -219,6 +220,24 @@ int upload_matrix(PpgEngine* e, int rows, int cols, int rows_pad, int cols_pad, 
     for (int r = 0; r < rows; ++r)
         for (int c = 0; c < cols; ++c) tmp[(size_t)r * cols_pad + c] = get(r, c);
     return upload(e, tmp.data(), n * 4, reinterpret_cast<void**>(dst));
+}
+
+// Token blocks (of 16) per wave for the token-tiled kernels: a workgroup
+// covers 64*nt tokens; pick the nt that minimises (rounds over the CUs) x
+// (per-round cost ~ nt, larger tiles being slightly more efficient because
+// each weight fragment read from LDS feeds nt MFMAs).
+int choose_nt(const PpgEngine* e, int M, int max_nt) {
+    if (e->ffn_nt >= 1) return std::min(e->ffn_nt, max_nt);
+    static const double eff[4] = {0, 0.7, 1.0, 1.1};
+    int best = 1;
+    double best_cost = 1e30;
+    for (int nt = 1; nt <= max_nt; ++nt) {
+        const int blocks = (M + 64 * nt - 1) / (64 * nt);
+        const int rounds = (blocks + e->num_cus - 1) / e->num_cus;
+        const double cost = rounds * nt / eff[nt];
+        if (cost < best_cost) { best_cost = cost; best = nt; }
+    }
+    return best;
 }
 
 Workspace layout(const PpgEngine* e, const PpgPlanInfo& info) {
@@ -442,7 +461,12 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     e->out_total_groups = round_up(5 * e->out_groups_per_tap, 2);
     if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
-    if (e->ffn_nt < 1 || e->ffn_nt > 3) e->ffn_nt = 2;
+    if (e->ffn_nt < 0 || e->ffn_nt > 3) e->ffn_nt = 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            e->num_cus = prop.multiProcessorCount;
+    }
 
     int rc;
     PpgEngine* E = e.get();
@@ -575,6 +599,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
     } while (0)
 
+    const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);
+
     // V^T padding columns and the K rows past the last token are read (masked)
     // by the attention tiles: keep them finite.
     HIP_OK(hipMemsetAsync(vt, 0, (size_t)H * ws.vt_ld * e->sz, s));
@@ -601,7 +627,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
         a.total_groups = e->in_total_groups;
         a.W = e->w_in; a.bias = e->b_in; a.N = H; a.pe = e->pe;
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, a, H / 256, s), "in-conv");
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, nt, a, H / 256, s), "in-conv");
     }
     const int hg = H / e->KG;   // K-groups of a hidden-wide row
     for (int l = 0; l < c.num_layers; ++l) {
@@ -613,7 +639,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
             a.W = d.wqkv; a.bias = d.bqkv; a.N = 3 * H;
             a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
-            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, a, 3 * H / 256, s), "qkv");
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, nt, a, 3 * H / 256, s), "qkv");
         }
         {
             Timed t(e, PPG_K_ATTENTION, s);
@@ -630,7 +656,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.act = ao; a.lda_bytes = H * e->sz;
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
             a.W = d.wo; a.bias = d.bo; a.N = H; a.gamma = d.g1; a.beta = d.e1;
-            LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, a, 1, s), "out-proj+LN");
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, nt, a, 1, s), "out-proj+LN");
         }
         {
             Timed t(e, PPG_K_FFN, s);
@@ -638,19 +664,19 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 FfnArgs a{};
                 a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
                 a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M;
-                LAUNCH_OK(ppg::launch_ffn(prec, a, e->ffn_nt, s), "ffn");
+                LAUNCH_OK(ppg::launch_ffn(prec, a, H == 256 ? nt : 1, s), "ffn");
             } else {
                 LinearArgs a = base_args();
                 a.act = act_x; a.lda_bytes = H * e->sz;
                 a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
                 a.W = d.w1; a.bias = d.b1; a.N = F; a.out_rows = hid; a.out_ld = F;
-                LAUNCH_OK(ppg::launch_linear(prec, EPI_RELU, 16, a, F / 256, s), "ffn1");
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RELU, 16, nt, a, F / 256, s), "ffn1");
                 LinearArgs b = base_args();
                 const int fg = F / e->KG;
                 b.act = hid; b.lda_bytes = F * e->sz;
                 b.groups_per_tap = fg; b.real_groups = fg; b.total_groups = fg;
                 b.W = d.w2; b.bias = d.b2; b.N = H; b.gamma = d.g2; b.beta = d.e2;
-                LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, b, 1, s), "ffn2+LN");
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, nt, b, 1, s), "ffn2+LN");
             }
         }
     }
@@ -662,7 +688,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.total_groups = e->out_total_groups;
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, a, 1, s), "out-conv+softmax");
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, nt, a, 1, s), "out-conv+softmax");
     }
 #undef LAUNCH_OK
     return PPG_OK;

@@ -541,11 +541,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
     const int NC = a.F / HC;
 
-    auto stage = [&](int c, char* buf) {
-        stage_tile<HC, ROW1, 4>(a.W1 + (size_t)c * 32768, (size_t)ROW1, buf, wave, lane);
-        stage_tile<H, ROW2, 4>(a.W2p + (size_t)c * ROW2, (size_t)a.F * P::kBytes, buf + 32768, wave, lane);
+    // LDS: W1 tiles at 0 / 32 KiB, W2 tiles at 64 / 96 KiB, b1 at 128 KiB
+    auto stage_w1 = [&](int c) {
+        stage_tile<HC, ROW1, 4>(a.W1 + (size_t)c * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
     };
-    stage(0, smem);
+    auto stage_w2 = [&](int c) {
+        stage_tile<H, ROW2, 4>(a.W2p + (size_t)c * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
+    };
+    stage_w1(0);
+    stage_w2(0);
+    if (NC > 1) stage_w1(1);
     for (int i = tid; i < a.F / 4; i += 256)
         reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
 
@@ -568,69 +573,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    dma_wait_barrier();
+    using LA = FragLayout<ROW1, HB>;
+    using LB = FragLayout<ROW2, NBH>;
+    constexpr int RA = XG * HB;          // fragments of phase A
+    constexpr int UNITS = HB * NT;       // pack units (one hidden 16-block of one token block)
+    constexpr int DEPTH = NT >= 3 ? 6 : 8;
+    const uint32_t lds0 = lds_addr(smem);
 
-    for (int c = 0; c < NC; ++c) {
-        const uint32_t lds1a = lds_addr(smem) + (c & 1) * 65536;
-        const uint32_t lds2a = lds1a + 32768;
-        // b1 of this chunk: read before the next chunk's DMA is issued (an
-        // ordinary LDS load behind an in-flight LDS DMA makes hipcc drain it)
+    // pack unit u = (hb, t): bias + ReLU on the phase-A accumulator, packed
+    // straight into the phase-B B-fragment (see header comment)
+    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NT], u32x4 (&b1f)[HB], u32x4 (&hf)[HG][NT]) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int hb = u / NT, t = u % NT;
+        const u32x4 bv = b1f[hb];
+        const float h0 = fmaxf(hsrc[hb][t][0] + __uint_as_float(bv.x), 0.f);
+        const float h1 = fmaxf(hsrc[hb][t][1] + __uint_as_float(bv.y), 0.f);
+        const float h2 = fmaxf(hsrc[hb][t][2] + __uint_as_float(bv.z), 0.f);
+        const float h3 = fmaxf(hsrc[hb][t][3] + __uint_as_float(bv.w), 0.f);
+        if constexpr (P::kIsBF16) {
+            if constexpr (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
+            else                  { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
+        } else {
+            hf[hb][t] = u32x4{__float_as_uint(h0), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+        }
+    };
+    // phase A of chunk c: h^T = W1c x^T (fragment i = (kg, hb)); the VALU of
+    // `filler(step)` is issued between the MFMAs so the matrix pipe stays fed
+    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NT], auto filler) {
+        uint32_t fba[LA::VAR];
+        LA::bases(lds0 + (c & 1) * 32768, idx, g, fba);
+        lds_stream<LA, RA, DEPTH>(fba, [&](auto ic, const u32x4& wf) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (i / HB == 0) P::mma0(hdst[i % HB][t], wf, xf[0][t]);
+                else P::mma(hdst[i % HB][t], wf, xf[i / HB][t]);
+            }
+            filler(ic);
+        });
+    };
+    // one chunk: [A(c+1) || pack(c)] -> B(c)
+    auto chunk = [&](int c, f32x4 (&hcur)[HB][NT], f32x4 (&hnext)[HB][NT]) {
         u32x4 b1f[HB];
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
             ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (c * HC + hb * 16 + 4 * g) * 4);
-        if (c + 1 < NC) stage(c + 1, smem + ((c + 1) & 1) * 65536);
+        if (c + 2 < NC) stage_w1(c + 2);
+        if (c + 1 < NC) stage_w2(c + 1);
+        u32x4 hf[HG][NT];
+        if (c + 1 < NC) {
+            phase_a(c + 1, hnext, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i == 0) {
+                    // stream step 0 waited on an LDS op younger than the b1 reads
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
+                }
+                // spread the UNITS pack units evenly over the RA stream steps
+                if constexpr ((i * UNITS) / RA != ((i + 1) * UNITS) / RA)
+                    pack_unit(std::integral_constant<int, (i * UNITS) / RA>{}, hcur, b1f, hf);
+            });
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
+            [&]<int... U>(std::integer_sequence<int, U...>) {
+                (pack_unit(std::integral_constant<int, U>{}, hcur, b1f, hf), ...);
+            }(std::make_integer_sequence<int, UNITS>{});
+        }
+        // phase B: y^T += W2c h^T ; fragment i = (kg, nb)
+        uint32_t fbb[LB::VAR];
+        LB::bases(lds0 + 65536 + (c & 1) * 32768, idx, g, fbb);
+        lds_stream<LB, HG * NBH, DEPTH>(fbb, [&](auto ic, const u32x4& wf) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) P::mma(yacc[i % NBH][t], wf, hf[i / NBH][t]);
+        });
+        dma_wait_barrier();
+    };
 
-        // phase A: h^T = W1c x^T ; fragment i = (kg, hb) = (i / HB, i % HB)
-        f32x4 hacc[HB][NT];
+    f32x4 h0[HB][NT], h1[HB][NT];
+    dma_wait_barrier();
+    phase_a(0, h0, [](auto) {});
+    __syncthreads();                      // W1 buffer 0 is re-filled by chunk 0's DMA
+    for (int c = 0; c < NC; ++c) {
+        chunk(c, h0, h1);
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) hacc[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        using LA = FragLayout<ROW1, HB>;
-        uint32_t fba[LA::VAR];
-        LA::bases(lds1a, idx, g, fba);
-        lds_stream<LA, XG * HB, 6>(
-            fba,
-            [&](auto ic, const u32x4& wf) {
-                constexpr int i = decltype(ic)::value;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) P::mma(hacc[i % HB][t], wf, xf[i / HB][t]);
-            });
-        // bias + ReLU, pack as phase-B fragments (the stream's last wait was
-        // lgkmcnt(0): the older b1 reads have landed)
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
-        u32x4 hf[HG][NT];
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb) {
-            const u32x4 bv = b1f[hb];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float h0 = fmaxf(hacc[hb][t][0] + __uint_as_float(bv.x), 0.f);
-                const float h1 = fmaxf(hacc[hb][t][1] + __uint_as_float(bv.y), 0.f);
-                const float h2 = fmaxf(hacc[hb][t][2] + __uint_as_float(bv.z), 0.f);
-                const float h3 = fmaxf(hacc[hb][t][3] + __uint_as_float(bv.w), 0.f);
-                if constexpr (P::kIsBF16) {
-                    if (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
-                    else        { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
-                } else {
-                    hf[hb][t] = u32x4{__float_as_uint(h0), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
-                }
-            }
-        }
-        // phase B: y^T += W2c h^T ; fragment i = (kg, nb) = (i / NBH, i % NBH)
-        using LB = FragLayout<ROW2, NBH>;
-        uint32_t fbb[LB::VAR];
-        LB::bases(lds2a, idx, g, fbb);
-        lds_stream<LB, HG * NBH, 6>(
-            fbb,
-            [&](auto ic, const u32x4& wf) {
-                constexpr int i = decltype(ic)::value;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) P::mma(yacc[i % NBH][t], wf, hf[i / NBH][t]);
-            });
-        dma_wait_barrier();
+            for (int t = 0; t < NT; ++t) h0[hb][t] = h1[hb][t];
     }
 
     resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
@@ -812,15 +843,22 @@ hipError_t launch_linear_t(const LinearArgs& a, int ypasses, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <class P, int NB, int EPI>
+hipError_t launch_linear_nt(int nt, const LinearArgs& a, int ypasses, hipStream_t s) {
+    if (nt == 1) return launch_linear_t<P, 1, NB, EPI>(a, ypasses, s);
+    if (nt == 3) return launch_linear_t<P, 3, NB, EPI>(a, ypasses, s);
+    return launch_linear_t<P, 2, NB, EPI>(a, ypasses, s);
+}
+
 template <class P>
-hipError_t launch_linear_p(int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s) {
+hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s) {
     switch (epi) {
-    case EPI_INCONV: return launch_linear_t<P, 2, 16, EPI_INCONV>(a, ypasses, s);
-    case EPI_QKV:    return launch_linear_t<P, 2, 16, EPI_QKV>(a, ypasses, s);
-    case EPI_RELU:   return launch_linear_t<P, 2, 16, EPI_RELU>(a, ypasses, s);
-    case EPI_OUTCONV:return launch_linear_t<P, 2, 3, EPI_OUTCONV>(a, ypasses, s);
+    case EPI_INCONV: return launch_linear_nt<P, 16, EPI_INCONV>(nt, a, ypasses, s);
+    case EPI_QKV:    return launch_linear_nt<P, 16, EPI_QKV>(nt, a, ypasses, s);
+    case EPI_RELU:   return launch_linear_nt<P, 16, EPI_RELU>(nt, a, ypasses, s);
+    case EPI_OUTCONV:return launch_linear_nt<P, 3, EPI_OUTCONV>(nt, a, ypasses, s);
     case EPI_RESLN:
-        if (nb == 16) return launch_linear_t<P, 2, 16, EPI_RESLN>(a, ypasses, s);
+        if (nb == 16) return launch_linear_nt<P, 16, EPI_RESLN>(nt, a, ypasses, s);
         if (nb == 32) return launch_linear_t<P, 1, 32, EPI_RESLN>(a, ypasses, s);
         return hipErrorInvalidValue;
     }
@@ -880,9 +918,9 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_linear(int precision, int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s) {
-    if (precision == PPG_PRECISION_BF16) return launch_linear_p<PrecBF16>(epi, nb, a, ypasses, s);
-    return launch_linear_p<PrecF32>(epi, nb, a, ypasses, s);
+hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s) {
+    if (precision == PPG_PRECISION_BF16) return launch_linear_p<PrecBF16>(epi, nb, nt, a, ypasses, s);
+    return launch_linear_p<PrecF32>(epi, nb, nt, a, ypasses, s);
 }
 
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s) {

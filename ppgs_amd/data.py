@@ -50,8 +50,8 @@ def pack_batches(lengths, max_frames=config.MAX_INFERENCE_FRAMES,
     count = len(lengths)
     if count == 0:
         return []
-    order = np.argsort(lengths, kind='stable')
     if mode == 'sorted':
+        order = np.argsort(lengths, kind='stable')
         batches, batch, longest = [], [], 0
         for index in order[::-1]:           # longest first: max is the first item
             length = int(lengths[index])
@@ -66,6 +66,9 @@ def pack_batches(lengths, max_frames=config.MAX_INFERENCE_FRAMES,
         return batches
     if mode != 'reference':
         raise ValueError(f'unknown packing mode {mode}')
+    # np.argsort's default (unstable) order on ties, as reference
+    # Dataset.buckets (dataset.py:115)
+    order = np.argsort(lengths)
     size = count // buckets
     pairs = np.stack((order, lengths[order])).T
     bucket_list = [pairs[i:i + size] for i in range(0, count, size)]
