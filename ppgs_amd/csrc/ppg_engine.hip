@@ -166,6 +166,7 @@ struct PpgEngine {
     int out_groups_per_tap = 0, out_total_groups = 0;
     int head_dim = 0;
     int ffn_nt = 0;       // 0 = pick per launch (choose_nt); 1..3 = forced
+    int lin_nt = 0;       // same for the linear/conv kernels
     int num_cus = 256;
     bool ffn_fused = true;
     std::vector<void*> allocs;
@@ -460,6 +461,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     e->out_groups_per_tap = H / e->KG;
     e->out_total_groups = round_up(5 * e->out_groups_per_tap, 2);
     if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
+    if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (e->ffn_nt < 0 || e->ffn_nt > 3) e->ffn_nt = 0;
     {
@@ -599,7 +601,13 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
     } while (0)
 
-    const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);
+    const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);     // fused FFN
+    // linear / conv kernels: measured best at C2 (two 256-register workgroups
+    // per CU): 32-token waves for the wide projections, 16-token waves where
+    // the epilogue dominates (LayerNorm, softmax scatter)
+    const bool forced = e->lin_nt >= 1 && e->lin_nt <= 3;
+    const int lnt = forced ? e->lin_nt : std::min(nt, 2);
+    const int lnt_ln = forced ? e->lin_nt : 1;
 
     // V^T padding columns and the K rows past the last token are read (masked)
     // by the attention tiles: keep them finite.
@@ -627,7 +635,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
         a.total_groups = e->in_total_groups;
         a.W = e->w_in; a.bias = e->b_in; a.N = H; a.pe = e->pe;
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, nt, a, H / 256, s), "in-conv");
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, lnt, a, H / 256, s), "in-conv");
     }
     const int hg = H / e->KG;   // K-groups of a hidden-wide row
     for (int l = 0; l < c.num_layers; ++l) {
@@ -639,7 +647,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
             a.W = d.wqkv; a.bias = d.bqkv; a.N = 3 * H;
             a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
-            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, nt, a, 3 * H / 256, s), "qkv");
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, lnt, a, 3 * H / 256, s), "qkv");
         }
         {
             Timed t(e, PPG_K_ATTENTION, s);
@@ -656,7 +664,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.act = ao; a.lda_bytes = H * e->sz;
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
             a.W = d.wo; a.bias = d.bo; a.N = H; a.gamma = d.g1; a.beta = d.e1;
-            LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, nt, a, 1, s), "out-proj+LN");
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, lnt_ln, a, 1, s), "out-proj+LN");
         }
         {
             Timed t(e, PPG_K_FFN, s);
@@ -670,13 +678,13 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 a.act = act_x; a.lda_bytes = H * e->sz;
                 a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
                 a.W = d.w1; a.bias = d.b1; a.N = F; a.out_rows = hid; a.out_ld = F;
-                LAUNCH_OK(ppg::launch_linear(prec, EPI_RELU, 16, nt, a, F / 256, s), "ffn1");
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RELU, 16, lnt, a, F / 256, s), "ffn1");
                 LinearArgs b = base_args();
                 const int fg = F / e->KG;
                 b.act = hid; b.lda_bytes = F * e->sz;
                 b.groups_per_tap = fg; b.real_groups = fg; b.total_groups = fg;
                 b.W = d.w2; b.bias = d.b2; b.N = H; b.gamma = d.g2; b.beta = d.e2;
-                LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, nt, b, 1, s), "ffn2+LN");
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, lnt_ln, b, 1, s), "ffn2+LN");
             }
         }
     }
@@ -688,7 +696,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.total_groups = e->out_total_groups;
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, nt, a, 1, s), "out-conv+softmax");
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, lnt_ln, a, 1, s), "out-conv+softmax");
     }
 #undef LAUNCH_OK
     return PPG_OK;

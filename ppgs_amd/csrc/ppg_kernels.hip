@@ -274,8 +274,10 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
 // global -> registers -> LDS (double buffered, one barrier per tile, loads
 // of tile s+1 issued before the MFMAs of tile s).
 // ---------------------------------------------------------------------------
+// NT <= 2 (and the 16-feature-block passes): capped at 256 registers so two
+// workgroups share a CU and cover each other's LDS / barrier / issue stalls.
 template <class P, int NT, int NB, int EPI>
-__global__ __launch_bounds__(256) void linear_kernel(LinearArgs a) {
+__global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = NB * 16 * 128;
 
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // over keys = per-lane partials + shuffles over the 4 lane groups.
 // ---------------------------------------------------------------------------
 template <class P, int NTQ, int DH>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWK = DH * P::kBytes;            // K tile row bytes
     constexpr int DG = ROWK / 64;                   // K-groups over head dim
@@ -758,33 +760,49 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 for (int t = 0; t < NTQ; ++t) P::mma(sacc[i % KB][t], kf, qf[i / KB][t]);
             });
 
+        // Online softmax in the exp2 domain: p = exp2(s*c - m*c), c = log2(e)/sqrt(d),
+        // one FMA + one v_exp_f32 per score; the running max is tracked on the raw
+        // scores (c > 0).  Masking code only runs for tiles that reach past the
+        // valid keys / the causal diagonal; O is rescaled only when a max moved.
         u32x4 pf[PG][NTQ];
+        const float c = a.scale_log2e;
+        const bool need_mask = (kt + 1) * KT > w.valid || (a.causal && (kt + 1) * KT > qw0);
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
             const int tq = qw0 + 16 * t + idx;
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * KT + kb * 16 + 4 * g + r;
+                        if (key >= w.valid || (a.causal && key > tq)) sacc[kb][t][r] = -INFINITY;
+                    }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * KT + kb * 16 + 4 * g + r;
-                    const bool masked = key >= w.valid || (a.causal && key > tq);
-                    const float s = masked ? -INFINITY : sacc[kb][t][r] * a.scale_log2e;
-                    sacc[kb][t][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                mx = fmaxf(fmaxf(mx, fmaxf(sacc[kb][t][0], sacc[kb][t][1])), fmaxf(sacc[kb][t][2], sacc[kb][t][3]));
             mx = wave_max_g(mx);
             const float mnew = fmaxf(mrun[t], mx);
-            const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-            const float alpha = exp2f(mrun[t] - msafe);
-            mrun[t] = mnew;
+            const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;       // fully masked so far: p = exp2(-inf) = 0
+            if (__any(mnew != mrun[t])) {
+                const float alpha = __builtin_amdgcn_exp2f(mrun[t] * c - mc);   // first tile: exp2(-inf) = 0
+                lrun[t] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
+                    oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
+                }
+                mrun[t] = mnew;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const float p0 = exp2f(sacc[kb][t][0] - msafe);
-                const float p1 = exp2f(sacc[kb][t][1] - msafe);
-                const float p2 = exp2f(sacc[kb][t][2] - msafe);
-                const float p3 = exp2f(sacc[kb][t][3] - msafe);
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][0], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][1], c, -mc));
+                const float p2 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][2], c, -mc));
+                const float p3 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][3], c, -mc));
                 psum += (p0 + p1) + (p2 + p3);
                 if constexpr (P::kIsBF16) {
                     if (kb & 1) { pf[kb >> 1][t].z = pack_bf16x2(p0, p1); pf[kb >> 1][t].w = pack_bf16x2(p2, p3); }
@@ -793,14 +811,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
                 }
             }
-            lrun[t] = lrun[t] * alpha + psum;
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
-                oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
-            }
+            lrun[t] += psum;
         }
-        // fragment i = (kg, db) = (i / DB, i % DB)
         using LV = FragLayout<ROWV, DB>;
         uint32_t fbv[LV::VAR];
         LV::bases(ldsv, idx, g, fbv);
