@@ -195,11 +195,12 @@ int ppg_frontend(int device, const float* audio, int batch, int samples,
 
 /*
  * Per-kernel-class timing with HIP events on the launch stream (used by
- * bench.py's roofline leg).  Enable, run, then read: total milliseconds and
- * launch count accumulated since the last reset.  Reading synchronises the
- * recorded events.
+ * bench.py's roofline leg).  `classes` is a bitmask of (1 << PPG_K_*), 0 =
+ * off, -1 = every class (each timed launch costs two event records on the
+ * stream).  Enable, run, then read: total milliseconds and launch count
+ * accumulated since the last reset.  Reading synchronises the recorded events.
  */
-int ppg_engine_profile(PpgEngine* engine, int enable);
+int ppg_engine_profile(PpgEngine* engine, int classes);
 int ppg_engine_profile_read(PpgEngine* engine, int kernel_class,
                             double* total_ms, int64_t* launches);
 int ppg_engine_profile_reset(PpgEngine* engine);

@@ -178,7 +178,7 @@ struct PpgEngine {
     uint64_t plan_stamp = 0;
     std::mutex mu;
     // profiling
-    bool profiling = false;
+    unsigned profiling = 0;          // bitmask of kernel classes to time
     std::vector<EventPair> events[PPG_K_COUNT];
     size_t events_used[PPG_K_COUNT] = {0};
 
@@ -310,7 +310,7 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
 struct Timed {
     PpgEngine* e; int cls; hipStream_t s; EventPair ev{}; bool on = false;
     Timed(PpgEngine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
-        if (!e->profiling) return;
+        if (!(e->profiling & (1u << cls))) return;
         auto& pool = e->events[cls];
         size_t& used = e->events_used[cls];
         if (used == pool.size()) {
@@ -735,7 +735,7 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
 
 int ppg_engine_profile(PpgEngine* e, int enable) {
     if (!e) return fail(PPG_EINVAL, "null engine");
-    e->profiling = enable != 0;
+    e->profiling = (unsigned)enable;
     return PPG_OK;
 }
 

@@ -848,8 +848,12 @@ hipError_t launch_linear_t(const LinearArgs& a, int ypasses, hipStream_t s) {
     const size_t lds = 2 * NB * 16 * 128;
     auto kern = linear_kernel<P, NT, NB, EPI>;
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        static bool configured = false;      // once per process: not a stream operation (graph capture)
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(blocks, ypasses), dim3(256), lds, s, a);
     return hipGetLastError();
@@ -882,8 +886,12 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
     auto kern = ffn_kernel<P, NT, NBH>;
     const size_t lds = 131072 + (size_t)a.F * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static size_t configured = 0;            // once per process and size: not a stream operation
+    if (configured < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }

@@ -263,8 +263,14 @@ class Engine:
         return out
 
     # -- per-kernel HIP-event timing (bench.py roofline leg) ----------------
-    def profile(self, enable=True):
-        _check(self._lib.ppg_engine_profile(self._handle, int(enable)))
+    def profile(self, enable=True, classes=None):
+        """Time launches with HIP events: every kernel class, or only the
+        named ones (each timed launch adds two event records to the stream)."""
+        mask = 0
+        if enable:
+            mask = -1 if classes is None else sum(
+                1 << KERNEL_CLASSES.index(name) for name in classes)
+        _check(self._lib.ppg_engine_profile(self._handle, mask))
         _check(self._lib.ppg_engine_profile_reset(self._handle))
 
     def profile_read(self):
