@@ -157,6 +157,7 @@ struct FfnArgs {
     int H;
     int F;
     int M;
+    unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
 };
 
 struct AttnItem {

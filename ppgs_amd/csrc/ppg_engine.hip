@@ -169,6 +169,7 @@ struct PpgEngine {
     int lin_nt = 0;       // same for the linear/conv kernels
     int num_cus = 256;
     bool ffn_fused = true;
+    unsigned long long* ffn_dbg = nullptr;
     std::vector<void*> allocs;
     float* pe = nullptr;
     char* w_in = nullptr; float* b_in = nullptr;
@@ -184,6 +185,19 @@ struct PpgEngine {
 
     ~PpgEngine() {
         (void)hipSetDevice(device);
+        if (ffn_dbg) {
+            unsigned long long h[128];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(h, ffn_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int w = 0; w < 4; ++w)
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned long long* t = h + (w * 4 + c) * 8;
+                        fprintf(stderr, "ffn timing wave %d chunk %d: dma-issue %llu  A+pack %llu  B %llu  vmcnt %llu  barrier %llu | total %llu\n",
+                                w, c + 8, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+                    }
+            }
+            (void)hipFree(ffn_dbg);
+        }
         for (auto& kv : plans) if (kv.second->buf) (void)hipFree(kv.second->buf);
         for (void* p : allocs) (void)hipFree(p);
         for (auto& v : events) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -463,6 +477,10 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
+    if (getenv("PPGS_AMD_FFN_TIMING")) {
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 1024));
+        HIP_OK(hipMemset(e->ffn_dbg, 0, 1024));
+    }
     if (e->ffn_nt < 0 || e->ffn_nt > 3) e->ffn_nt = 0;
     {
         hipDeviceProp_t prop;
@@ -671,7 +689,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             if (e->ffn_fused) {
                 FfnArgs a{};
                 a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
-                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M;
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
                 LAUNCH_OK(ppg::launch_ffn(prec, a, H == 256 ? nt : 1, s), "ffn");
             } else {
                 LinearArgs a = base_args();

@@ -544,11 +544,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int NC = a.F / HC;
 
     // LDS: W1 tiles at 0 / 32 KiB, W2 tiles at 64 / 96 KiB, b1 at 128 KiB
+    // The sum over hidden chunks is order-free: workgroup b walks the chunks
+    // starting at its own offset, so that the CUs of one XCD (b, b+8, b+16, ...)
+    // do not all pull the same 64 KiB of weights through the same L2 lines at
+    // the same moment.
+    const int rot = (blockIdx.x >> 3) % NC;
+    auto hidden_chunk = [&](int c) { const int r = c + rot; return r >= NC ? r - NC : r; };
     auto stage_w1 = [&](int c) {
-        stage_tile<HC, ROW1, 4>(a.W1 + (size_t)c * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
+        stage_tile<HC, ROW1, 4>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
     };
     auto stage_w2 = [&](int c) {
-        stage_tile<H, ROW2, 4>(a.W2p + (size_t)c * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
+        stage_tile<H, ROW2, 4>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
     };
     stage_w1(0);
     stage_w2(0);
@@ -615,13 +621,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
     };
     // one chunk: [A(c+1) || pack(c)] -> B(c)
+#ifdef PPG_FFN_TIMING
+    auto stamp = [&](int c, int k) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && c >= 8 && c < 12)
+            a.dbg[(wave * 4 + (c - 8)) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](int, int) {};
+#endif
     auto chunk = [&](int c, f32x4 (&hcur)[HB][NT], f32x4 (&hnext)[HB][NT]) {
+        stamp(c, 0);
         u32x4 b1f[HB];
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
-            ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (c * HC + hb * 16 + 4 * g) * 4);
+            ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
         if (c + 2 < NC) stage_w1(c + 2);
         if (c + 1 < NC) stage_w2(c + 1);
+        stamp(c, 1);
         u32x4 hf[HG][NT];
         if (c + 1 < NC) {
             phase_a(c + 1, hnext, [&](auto ic) {
@@ -643,6 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 (pack_unit(std::integral_constant<int, U>{}, hcur, b1f, hf), ...);
             }(std::make_integer_sequence<int, UNITS>{});
         }
+        stamp(c, 2);
         // phase B: y^T += W2c h^T ; fragment i = (kg, nb)
         uint32_t fbb[LB::VAR];
         LB::bases(lds0 + 65536 + (c & 1) * 32768, idx, g, fbb);
@@ -651,7 +668,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int t = 0; t < NT; ++t) P::mma(yacc[i % NBH][t], wf, hf[i / NBH][t]);
         });
-        dma_wait_barrier();
+        stamp(c, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(c, 4);
+        __syncthreads();
+        stamp(c, 5);
     };
 
     f32x4 h0[HB][NT], h1[HB][NT];

@@ -349,3 +349,31 @@ def test_c5_causal_streaming_chunks_and_graph_replay():
     assert np.abs(static_out[:8].cpu().numpy() - ref).max() < FP32_TOL
     again = engine.encode(static_in, lengths)
     assert (again - static_out).abs().max() == 0
+
+
+def test_large_ragged_batch_and_legacy_mode():
+    """Many windows (B=96 x T=2600 -> 7 windows per item, ~270k token rows),
+    and legacy (unchunked) mode on a 1200-frame item: finite, normalised, and
+    spot-checked against the oracle."""
+    engine, state = eng(precision='bf16')
+    gen = torch.Generator().manual_seed(3)
+    B, T = 96, 2600
+    lengths = torch.randint(1, T + 1, (B,), generator=gen).tolist()
+    lengths[0] = T
+    feats = torch.randn(B, 80, T, generator=gen).half()
+    out = engine.encode(feats.cuda(), lengths)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and (out.sum(1) - 1).abs().max() < 1e-5
+    rows = [0, 41, 95]
+    ref = O.from_features(state, feats[rows], [lengths[i] for i in rows]).numpy()
+    # the oracle batch has the same T, so window plans agree row by row
+    assert np.abs(out[rows].cpu().numpy() - ref).max() < BF16_TOL
+    fp32, _ = eng()
+    f = torch.randn(1, 80, 1200, generator=gen).half()
+    legacy = fp32.encode(f.cuda(), [1200], legacy_mode=True).cpu().numpy()
+    ref = O.from_features(state, f, [1200], legacy_mode=True).numpy()
+    assert np.abs(legacy - ref).max() < FP32_TOL
+    chunked = fp32.encode(f.cuda(), [1200]).cpu().numpy()
+    assert np.abs(legacy - chunked).max() > 1e-4          # the two modes really differ
+    with pytest.raises(ValueError):
+        fp32.encode(torch.zeros(1, 80, 5000).half().cuda(), [5000], legacy_mode=True)
