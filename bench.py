@@ -54,11 +54,23 @@ def parse():
 
 def cpu_baseline(state, seconds):
     """Oracle (CPU port of the reference path, fp32, autocast off) on a
-    bounded sample: batches of 4 x 160000 samples for about `seconds`."""
+    bounded sample: batches of 4 x 160000 samples for about `seconds`, at the
+    torch thread count that is fastest on this host (the default -- one thread
+    per logical core -- oversubscribes the small GEMMs)."""
     from oracle import ppg_oracle
     generator = torch.Generator().manual_seed(1234)
     audio = 0.1 * torch.randn(4, 1, SAMPLES, generator=generator)
-    ppg_oracle.from_audio(state, audio[:1, :, :16000])          # warm-up
+    default_threads = torch.get_num_threads()
+    best = (float('inf'), default_threads)
+    for threads in sorted({default_threads, 64, 32, 16}):
+        if threads > default_threads:
+            continue
+        torch.set_num_threads(threads)
+        ppg_oracle.from_audio(state, audio[:1, :, :16000])      # warm-up
+        start = time.perf_counter()
+        ppg_oracle.from_audio(state, audio[:2])
+        best = min(best, (time.perf_counter() - start, threads))
+    torch.set_num_threads(best[1])
     start = time.perf_counter()
     batches = 0
     while True:
@@ -67,15 +79,39 @@ def cpu_baseline(state, seconds):
         elapsed = time.perf_counter() - start
         if elapsed > seconds or batches >= 64:
             break
+    torch.set_num_threads(default_threads)
     return {
         'value': batches * 4 * FRAMES / elapsed,
         'unit': 'frames/s',
-        'cores': torch.get_num_threads(),
+        'cores': best[1],
         'kind': 'port',
         'sample': f'{batches} batches of 4 x {FRAMES} frames '
                   f'(mel frontend + encoder + softmax, fp32 CPU oracle), '
-                  f'{elapsed:.1f} s on {os.cpu_count()} logical cores',
+                  f'{elapsed:.1f} s with {best[1]} torch threads on '
+                  f'{os.cpu_count()} logical cores',
     }
+
+
+def pmc_traffic(kernel='ffn_kernel'):
+    """HBM-side bytes per launch of the dominant kernel from the newest
+    committed rocprofv3 PMC summary (profiles/r*_pmc_summary.txt; separate
+    --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 reports half of
+    a wide coalesced read, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.txt')))
+    if not files:
+        return None
+    fetch = write = None
+    for line in open(files[-1]):
+        if line.startswith(kernel):
+            m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
+            fetch = float(m.group(1)) if m else fetch
+            m = re.search(r'WRITE_SIZE=([0-9.e+]+)', line)
+            write = float(m.group(1)) if m else write
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
 
 
 def main():
@@ -174,7 +210,7 @@ def main():
                 'peak': peak,
                 'unit': 'TFLOP/s',
                 'frac': ffn_tflops / peak,
-                'traffic': None,
+                'traffic': pmc_traffic(),
                 'flops_per_launch': ffn_flops,
                 'mean_launch_ms': ffn_ms / max(ffn_launches, 1),
             },
