@@ -158,6 +158,7 @@ struct FfnArgs {
     int F;
     int M;
     unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
+    int variant;              // 0: one wave per SIMD (ffn_kernel); 1: A/B wave pairs (ffn_ab_kernel)
 };
 
 struct AttnItem {

@@ -169,6 +169,7 @@ struct PpgEngine {
     int lin_nt = 0;       // same for the linear/conv kernels
     int num_cus = 256;
     bool ffn_fused = true;
+    int ffn_variant = 0;
     unsigned long long* ffn_dbg = nullptr;
     std::vector<void*> allocs;
     float* pe = nullptr;
@@ -477,6 +478,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
+    if (const char* s = getenv("PPGS_AMD_FFN_AB")) e->ffn_variant = atoi(s);
     if (getenv("PPGS_AMD_FFN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 1024));
         HIP_OK(hipMemset(e->ffn_dbg, 0, 1024));
@@ -689,7 +691,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             if (e->ffn_fused) {
                 FfnArgs a{};
                 a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
-                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr; a.variant = e->ffn_variant;
                 LAUNCH_OK(ppg::launch_ffn(prec, a, H == 256 ? nt : 1, s), "ffn");
             } else {
                 LinearArgs a = base_args();

@@ -56,20 +56,47 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // LDS image: 16-byte slot (row, pp) holds global piece p = swz(row, pp); the
 // image is lane-linear per wave-instruction (1 KiB pieces), the swizzle is
 // applied on the SOURCE address and again (same involution) on the reads.
+//
+// Addressing: piece = i*NWAVES + wave.  The swizzle pattern of a piece repeats
+// with PERIOD pieces (= 16 rows), so  source(piece) = gsrc
+//     + (piece / PERIOD) * 16 rows * gstride            wave-uniform
+//     + lane_off[piece % PERIOD]                        per lane, <= V variants per wave
+// i.e. a handful of 32-bit lane offsets instead of one 64-bit address per
+// piece (which the compiler hoists out of the tile loop and then spills).
 template <int ROWS, int ROW_BYTES, int NWAVES>
-__device__ __forceinline__ void stage_tile(const char* gsrc, size_t gstride, char* lds, int wave, int lane) {
-    constexpr int S = ROW_BYTES / 16;
-    constexpr int PIECES = ROWS * S / 64;
+struct TileDma {
+    static constexpr int S = ROW_BYTES / 16;                       // 16-byte slots per row
+    static constexpr int PIECES = ROWS * S / 64;
+    static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;
+    static constexpr int PERIOD = ROW_BYTES >= 256 ? 16 * S / 64 : 1;
+    static constexpr int ROWS_PER_PERIOD = PERIOD * 64 / S;        // 16, or rows per piece when PERIOD == 1
+    static constexpr int V = PERIOD > NWAVES ? PERIOD / NWAVES : 1;
     static_assert((ROWS * S) % 64 == 0, "tile must be a whole number of 1 KiB pieces");
+    static_assert(PERIOD <= NWAVES || PERIOD % NWAVES == 0, "pattern period vs wave count");
+    static_assert(ROW_BYTES >= 256 ? ROWS_PER_PERIOD == 16 : true, "swizzle period");
+
+    static __device__ __forceinline__ void run(const char* gsrc, size_t gstride, char* lds, int wave, int lane) {
+        uint32_t lane_off[V];
 #pragma unroll
-    for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
-        const int piece = i * NWAVES + wave;
-        if (PIECES % NWAVES == 0 || piece < PIECES) {
-            const int slot = piece * 64 + lane;
+        for (int v = 0; v < V; ++v) {
+            const int r = (v * NWAVES + wave) % PERIOD;            // pattern index of pieces i = v (mod V)
+            const int slot = r * 64 + lane;
             const int row = slot / S, pp = slot % S;
-            glds16(gsrc + (size_t)row * gstride + (swz<ROW_BYTES>(row, pp) << 4), lds + piece * 1024);
+            lane_off[v] = (uint32_t)(row * gstride) + (uint32_t)(swz<ROW_BYTES>(row, pp) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int piece = i * NWAVES + wave;
+            if (PIECES % NWAVES == 0 || piece < PIECES) {
+                const size_t base = (size_t)(piece / PERIOD) * ROWS_PER_PERIOD * gstride;
+                glds16(gsrc + base + lane_off[i % V], lds + piece * 1024);
+            }
         }
     }
+};
+template <int ROWS, int ROW_BYTES, int NWAVES>
+__device__ __forceinline__ void stage_tile(const char* gsrc, size_t gstride, char* lds, int wave, int lane) {
+    TileDma<ROWS, ROW_BYTES, NWAVES>::run(gsrc, gstride, lds, wave, lane);
 }
 
 // All DMA of this wave landed + workgroup barrier.
@@ -142,6 +169,32 @@ __device__ __forceinline__ void lds_stream_prime(u32x4 (&ring)[D], const uint32_
         lds_stream_prime<L, I + 1, R, D>(ring, fb);
     }
 }
+// Stream over the NBLK fragments of one K-group kg (runtime-free: kg is a
+// constant after unrolling at the call site) of a FragLayout<ROW, NBLK> tile.
+template <class L, int KG, int I, int NBLK, int D, class USE>
+__device__ __forceinline__ void lds_group_step(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR], USE& use) {
+    if constexpr (I < NBLK) {
+        lgkm_wait<(NBLK - 1 - I < D - 1) ? (NBLK - 1 - I) : (D - 1)>(ring[I % D]);
+        use(std::integral_constant<int, I>{}, ring[I % D]);
+        if constexpr (I + D < NBLK) ds_read_b128_asm<L::imm(KG * NBLK + I + D)>(ring[I % D], fb[L::variant(KG * NBLK + I + D)]);
+        lds_group_step<L, KG, I + 1, NBLK, D>(ring, fb, use);
+    }
+}
+template <class L, int KG, int I, int NBLK, int D>
+__device__ __forceinline__ void lds_group_prime(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR]) {
+    if constexpr (I < D && I < NBLK) {
+        ds_read_b128_asm<L::imm(KG * NBLK + I)>(ring[I], fb[L::variant(KG * NBLK + I)]);
+        lds_group_prime<L, KG, I + 1, NBLK, D>(ring, fb);
+    }
+}
+template <class L, int NBLK, int D, class USE>
+__device__ __forceinline__ void lds_stream_group(const uint32_t (&fb)[L::VAR], int kg, USE use) {
+    u32x4 ring[D];
+    // kg is 0 or 1 at every call site (fully unrolled loops)
+    if (kg == 0) { lds_group_prime<L, 0, 0, NBLK, D>(ring, fb); lds_group_step<L, 0, 0, NBLK, D>(ring, fb, use); }
+    else         { lds_group_prime<L, 1, 0, NBLK, D>(ring, fb); lds_group_step<L, 1, 0, NBLK, D>(ring, fb, use); }
+}
+
 template <class L, int R, int D, class USE>
 __device__ __forceinline__ void lds_stream(const uint32_t (&fb)[L::VAR], USE use) {
     u32x4 ring[D];
@@ -691,6 +744,196 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ---------------------------------------------------------------------------
+// Fused FFN, wave-specialised variant ("A/B waves"), two waves per SIMD.
+//
+// Workgroup = 8 waves = 4 pairs; pair p owns 16*NT tokens.  Wave p (an
+// "A wave") computes phase A, h^T = relu(W1c x^T + b1), for its pair's tokens
+// and hands the packed bf16 B-fragments to wave p+4 (the "B wave", same SIMD:
+// a workgroup's waves are dealt to the SIMDs cyclically) through LDS; the B
+// wave accumulates y^T += W2c h^T and does the residual + LayerNorm epilogue.
+// A waves run one hidden chunk ahead of B waves.  Each role needs <= 256
+// registers (x fragments + h accumulators | y accumulators), so both waves of
+// a SIMD are resident and each covers the other's LDS waits, DMA issue
+// (global_load_lds blocks the issuing wave ~60 cycles a piece), ReLU/pack
+// VALU and barrier skew -- what the single-wave ffn_kernel cannot hide.
+//
+// Interval i (i = 0 .. NC):  A waves: A(i)      reads W1 tile i
+//                            B waves: B(i-1)    reads W2 tile i-1, h(i-1) in registers
+//   both issue their share of the DMA for W1(i+1) and W2(i) at interval start
+//   barrier #1 (DMA landed, h(i-1) consumed) -> A waves write h(i) to LDS
+//   barrier #2 -> B waves load h(i) into registers
+// LDS: W1 x2 (64 KiB) | W2 x2 (64 KiB) | h hand-off (4 pairs) | b1.
+// ---------------------------------------------------------------------------
+template <class P, int NT, int NBH>
+__global__ __launch_bounds__(512, 2) void ffn_ab_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = NBH * 16;
+    constexpr int ROW1 = H * P::kBytes;
+    constexpr int XG = ROW1 / 64;
+    constexpr int HC = 32768 / ROW1;
+    constexpr int HB = HC / 16;
+    constexpr int ROW2 = HC * P::kBytes;
+    constexpr int HG = ROW2 / 64;
+    constexpr int HBUF_PAIR = HG * NT * 1024;        // one 1 KiB fragment per (kg, t)
+    char* ldsh = smem + 131072;
+    char* ldsb1 = ldsh + 4 * HBUF_PAIR;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
+    const int role = wave >> 2;                                    // 0 = A wave, 1 = B wave
+    const int pair = wave & 3;
+    const int idx = lane & 15;
+    const int g = lane >> 4;
+    const int tok0 = (blockIdx.x * 4 + pair) * 16 * NT;
+    const int NC = a.F / HC;
+    const uint32_t lds0 = lds_addr(smem);
+    char* hpair = ldsh + pair * HBUF_PAIR;
+
+    const int rot = (blockIdx.x >> 3) % NC;
+    auto hidden_chunk = [&](int c) { const int r = c + rot; return r >= NC ? r - NC : r; };
+    // all 8 waves share the DMA of a tile (4 pieces each)
+    auto stage_w1 = [&](int c) {
+        stage_tile<HC, ROW1, 8>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
+    };
+    auto stage_w2 = [&](int c) {
+        stage_tile<H, ROW2, 8>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
+    };
+    auto interval_dma = [&](int i) {
+        if (i + 1 < NC) stage_w1(i + 1);
+        if (i < NC) stage_w2(i);
+    };
+
+    stage_w1(0);
+    for (int i = tid; i < a.F / 4; i += 512)
+        reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
+
+    using LA = FragLayout<ROW1, HB>;
+    using LB = FragLayout<ROW2, NBH>;
+
+    if (role == 0) {
+        // ------------------------------ A waves -----------------------------
+        const char* actp = P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X);
+        u32x4 xf[XG][NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int m = tok0 + 16 * t + idx;
+#pragma unroll
+            for (int kg = 0; kg < XG; ++kg) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (m < a.M) v = *reinterpret_cast<const u32x4*>(actp + (size_t)m * ROW1 + kg * 64 + g * 16);
+                xf[kg][t] = v;
+            }
+        }
+        dma_wait_barrier();
+        for (int i = 0; i <= NC; ++i) {
+            u32x4 hf[HG][NT];
+            if (i < NC) {
+                u32x4 b1f[HB];
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+                    ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (hidden_chunk(i) * HC + hb * 16 + 4 * g) * 4);
+                interval_dma(i);
+                f32x4 hacc[HB][NT];
+                uint32_t fba[LA::VAR];
+                LA::bases(lds0 + (i & 1) * 32768, idx, g, fba);
+                lds_stream<LA, XG * HB, 6>(fba, [&](auto ic, const u32x4& wf) {
+                    constexpr int s_ = decltype(ic)::value;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (s_ / HB == 0) P::mma0(hacc[s_ % HB][t], wf, xf[0][t]);
+                        else P::mma(hacc[s_ % HB][t], wf, xf[s_ / HB][t]);
+                    }
+                });
+                // the stream's last wait was lgkmcnt(0): the older b1 reads landed
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) {
+                    const u32x4 bv = b1f[hb];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float h0 = fmaxf(hacc[hb][t][0] + __uint_as_float(bv.x), 0.f);
+                        const float h1 = fmaxf(hacc[hb][t][1] + __uint_as_float(bv.y), 0.f);
+                        const float h2 = fmaxf(hacc[hb][t][2] + __uint_as_float(bv.z), 0.f);
+                        const float h3 = fmaxf(hacc[hb][t][3] + __uint_as_float(bv.w), 0.f);
+                        if constexpr (P::kIsBF16) {
+                            if (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
+                            else        { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
+                        } else {
+                            hf[hb][t] = u32x4{__float_as_uint(h0), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+                        }
+                    }
+                }
+            } else {
+                interval_dma(i);
+            }
+            dma_wait_barrier();                         // barrier #1
+            if (i < NC) {
+#pragma unroll
+                for (int kg = 0; kg < HG; ++kg)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        *reinterpret_cast<u32x4*>(hpair + ((kg * NT + t) * 64 + lane) * 16) = hf[kg][t];
+            }
+            __syncthreads();                            // barrier #2
+        }
+    } else {
+        // ------------------------------ B waves -----------------------------
+        f32x4 yacc[NBH][NT];
+#pragma unroll
+        for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dma_wait_barrier();
+        for (int i = 0; i <= NC; ++i) {
+            if (i >= 1) {
+                // h(i-1): written by the A wave before barrier #2 of the previous
+                // interval.  Its first K-group is loaded before this interval's
+                // DMA is issued (an ordinary LDS load behind an in-flight LDS DMA
+                // makes hipcc drain the DMA); later groups by asm reads.
+                constexpr int DB = NT >= 3 ? 4 : 6;
+                u32x4 hf[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    hf[t] = *reinterpret_cast<const u32x4*>(hpair + (t * 64 + lane) * 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(hf[t]));
+                interval_dma(i);
+#pragma unroll
+                for (int kg = 0; kg < HG; ++kg) {
+                    // fragments of W2 tile rows for K-group kg: a FragLayout over
+                    // the [rows][ROW2] tile restricted to one group (i -> nb)
+                    uint32_t fbb[LB::VAR];
+                    LB::bases(lds0 + 65536 + ((i - 1) & 1) * 32768, idx, g, fbb);
+                    u32x4 hnext[NT];
+                    if (kg + 1 < HG) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            ds_read_b128_asm<0>(hnext[t], lds_addr(hpair) + (((kg + 1) * NT + t) * 64 + lane) * 16);
+                    }
+                    lds_stream_group<LB, NBH, DB>(fbb, kg, [&](auto ic, const u32x4& wf) {
+                        constexpr int s_ = decltype(ic)::value;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) P::mma(yacc[s_][t], wf, hf[t]);
+                    });
+                    if (kg + 1 < HG) {
+                        // the stream's last wait was lgkmcnt(0): hnext landed
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { asm volatile("" : "+v"(hnext[t])); hf[t] = hnext[t]; }
+                    }
+                }
+            } else {
+                interval_dma(i);
+            }
+            dma_wait_barrier();                         // barrier #1
+            __syncthreads();                            // barrier #2
+        }
+        resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Attention for one (window, head, query tile).  Transposed orientation:
 //   S^T[key][q] = K q^T   (A = K rows from LDS,   B = Q rows in registers)
 //   O^T[d][q]  += V^T P^T (A = V^T rows from LDS, B = P^T = exp(S^T - m))
@@ -917,8 +1160,28 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <class P, int NT, int NBH>
+hipError_t launch_ffn_ab_t(const FfnArgs& a, hipStream_t s) {
+    const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
+    auto kern = ffn_ab_kernel<P, NT, NBH>;
+    const size_t lds = 131072 + 4 * (size_t)((NBH * 16 * P::kBytes >= 1024 && NBH == 32 ? 1 : 2) * NT * 1024) + (size_t)a.F * 4;
+    static size_t configured = 0;
+    if (configured < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 template <class P>
 hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
+    if (a.variant == 1 && a.H == 256) {
+        if (nt == 1) return launch_ffn_ab_t<P, 1, 16>(a, s);
+        if (nt == 3) return launch_ffn_ab_t<P, 3, 16>(a, s);
+        return launch_ffn_ab_t<P, 2, 16>(a, s);
+    }
     if (a.H == 256) {
         if (nt == 1) return launch_ffn_t<P, 1, 16>(a, s);
         if (nt == 3) return launch_ffn_t<P, 3, 16>(a, s);
