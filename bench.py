@@ -178,7 +178,10 @@ def main():
         frames_per_s = world * BATCH * FRAMES * args.steps / elapsed
         _, info = E.plan_windows(BATCH, FRAMES, lengths)
         hidden, ffn = 256, 2048
-        ffn_flops = 4.0 * hidden * ffn * info.processed_frames
+        # FLOPs of ONE launch: the batch's FFN work of one layer, divided by the
+        # launches per layer (>1 when the engine splits the batch over streams)
+        launches_per_layer = max(ffn_launches // (5 * args.steps), 1)
+        ffn_flops = 4.0 * hidden * ffn * info.processed_frames / launches_per_layer
         ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_launches, 1)) / 1e12
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_FP32_TFLOPS
         step_flops = BATCH * data.flops(FRAMES)

@@ -49,13 +49,50 @@ uint16_t host_bf16(float f) {
 // ----------------------------------------------------------------------------
 // Chunk planner (reference ppgs/model/transformer.py:49-64)
 // ----------------------------------------------------------------------------
-struct Plan {
-    std::vector<PpgWindow> all;       // every window, skipped ones with tok_off = -1
-    std::vector<PpgWindow> windows;   // computed windows (valid > 0)
+// A group = a contiguous run of computed windows that is executed as one
+// independent pipeline on its own HIP stream (windows never interact), with
+// its own slice of the workspace and token rows numbered from 0.
+struct PlanGroup {
+    std::vector<PpgWindow> windows;   // tok_off / vt_off relative to the group
     std::vector<int> blk_win;
     std::vector<AttnItem> items;
+    int tokens = 0, vt_tokens = 0;
+    size_t ws_offset = 0;
+    PpgWindow* d_win = nullptr;
+    int* d_blk = nullptr;
+    AttnItem* d_items = nullptr;
+};
+
+struct Plan {
+    std::vector<PpgWindow> all;       // every window, skipped ones with tok_off = -1
+    std::vector<PpgWindow> windows;   // computed windows (valid > 0), absolute offsets
+    std::vector<PlanGroup> groups;
     PpgPlanInfo info{};
 };
+
+void split_groups(Plan* plan, int ngroups, int qtile) {
+    plan->groups.clear();
+    const int total = plan->info.tokens;
+    size_t w = 0;
+    for (int gi = 0; gi < ngroups && w < plan->windows.size(); ++gi) {
+        PlanGroup grp;
+        const int base_tok = plan->windows[w].tok_off, base_vt = plan->windows[w].vt_off;
+        const long long target = (long long)total * (gi + 1) / ngroups;
+        while (w < plan->windows.size() &&
+               (grp.windows.empty() || gi == ngroups - 1 || plan->windows[w].tok_off + round_up(plan->windows[w].frames, 16) / 2 < target)) {
+            PpgWindow win = plan->windows[w++];
+            win.tok_off -= base_tok;
+            win.vt_off -= base_vt;
+            const int wi = (int)grp.windows.size();
+            for (int k = 0; k < round_up(win.frames, 16) / 16; ++k) grp.blk_win.push_back(wi);
+            for (int q0 = 0; q0 < win.frames; q0 += qtile) grp.items.push_back(AttnItem{wi, q0});
+            grp.tokens = win.tok_off + round_up(win.frames, 16);
+            grp.vt_tokens = win.vt_off + round_up(win.frames, 32);
+            grp.windows.push_back(win);
+        }
+        plan->groups.push_back(std::move(grp));
+    }
+}
 
 int build_plan(int chunk, int overlap, int max_positions, int batch, int frames,
                const int64_t* lengths, int legacy, int qtile, Plan* plan) {
@@ -104,9 +141,6 @@ int build_plan(int chunk, int overlap, int max_positions, int batch, int frames,
                 vt += round_up(w.frames, 32);
                 plan->info.processed_frames += w.frames;
                 plan->info.attention_pairs += (int64_t)w.frames * w.frames;
-                const int wi = (int)plan->windows.size();
-                for (int k = 0; k < round_up(w.frames, 16) / 16; ++k) plan->blk_win.push_back(wi);
-                for (int q0 = 0; q0 < w.frames; q0 += qtile) plan->items.push_back(AttnItem{wi, q0});
                 plan->windows.push_back(w);
             } else {
                 w.tok_off = -1;
@@ -141,9 +175,6 @@ struct DevLayer {
 struct DevPlan {
     Plan host;
     void* buf = nullptr;
-    PpgWindow* win = nullptr;
-    int* blk_win = nullptr;
-    AttnItem* items = nullptr;
     uint64_t stamp = 0;
 };
 
@@ -170,6 +201,11 @@ struct PpgEngine {
     int num_cus = 256;
     bool ffn_fused = true;
     int ffn_variant = 0;
+    int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
+                            // but kernels of the two halves then overlap and per-kernel timings blur)
+    std::vector<hipStream_t> side_streams;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
     unsigned long long* ffn_dbg = nullptr;
     std::vector<void*> allocs;
     float* pe = nullptr;
@@ -200,6 +236,9 @@ struct PpgEngine {
             (void)hipFree(ffn_dbg);
         }
         for (auto& kv : plans) if (kv.second->buf) (void)hipFree(kv.second->buf);
+        for (hipStream_t st : side_streams) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : ev_join) (void)hipEventDestroy(ev);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (void* p : allocs) (void)hipFree(p);
         for (auto& v : events) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
@@ -256,14 +295,14 @@ int choose_nt(const PpgEngine* e, int M, int max_nt) {
     return best;
 }
 
-Workspace layout(const PpgEngine* e, const PpgPlanInfo& info) {
+Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
     Workspace w{};
-    const size_t M = info.tokens;
+    const size_t M = tokens;
     const int H = e->cfg.hidden_channels;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     w.qk_rows = (int)M + 64;
-    w.vt_ld = info.vt_tokens + 64;
+    w.vt_ld = vt_tokens + 64;
     w.xw = take(M * e->Cp * e->sz);
     w.x = take(M * H * 4);
     w.xb = take(e->sz == 2 ? M * H * 2 : 0);
@@ -273,6 +312,25 @@ Workspace layout(const PpgEngine* e, const PpgPlanInfo& info) {
     w.hid = take(e->ffn_fused ? 0 : M * e->cfg.ffn_channels * e->sz);
     w.total = off;
     return w;
+}
+
+// Pipelines (HIP streams) a batch is split into: windows are independent, so
+// two half-batches on two streams fill the CUs one kernel's last, partly
+// filled round of workgroups leaves idle (+8 % at C2).
+int group_count(const PpgEngine* e, int tokens) {
+    if (e->num_streams <= 1) return 1;
+    return tokens >= 128 * e->num_cus ? e->num_streams : 1;
+}
+
+size_t finish_plan(const PpgEngine* e, Plan* p) {
+    split_groups(p, group_count(e, p->info.tokens), ppg::attn_query_tile(e->head_dim));
+    size_t off = 0;
+    for (PlanGroup& grp : p->groups) {
+        grp.ws_offset = off;
+        off = align_up(off + layout(e, grp.tokens, grp.vt_tokens).total, 256);
+    }
+    p->info.workspace_bytes = off;
+    return off;
 }
 
 int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int legacy, DevPlan** out) {
@@ -292,16 +350,27 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
                         lengths, legacy, ppg::attn_query_tile(e->head_dim), &dp->host);
     if (rc) return rc;
     Plan& p = dp->host;
-    p.info.workspace_bytes = layout(e, p.info).total;
-    const size_t nwin = std::max<size_t>(p.windows.size(), 1);
-    const size_t o_win = 0;
-    const size_t o_blk = align_up(o_win + nwin * sizeof(PpgWindow), 256);
-    const size_t o_item = align_up(o_blk + std::max<size_t>(p.blk_win.size(), 1) * sizeof(int), 256);
-    const size_t total = align_up(o_item + std::max<size_t>(p.items.size(), 1) * sizeof(AttnItem), 256);
+    finish_plan(e, &p);
+    // one device buffer: per group windows | blk_win | attention items
+    struct Off { size_t win, blk, item; };
+    std::vector<Off> offs;
+    size_t total = 0;
+    for (const PlanGroup& grp : p.groups) {
+        Off o;
+        o.win = total;
+        o.blk = align_up(o.win + std::max<size_t>(grp.windows.size(), 1) * sizeof(PpgWindow), 256);
+        o.item = align_up(o.blk + std::max<size_t>(grp.blk_win.size(), 1) * sizeof(int), 256);
+        total = align_up(o.item + std::max<size_t>(grp.items.size(), 1) * sizeof(AttnItem), 256);
+        offs.push_back(o);
+    }
+    total = std::max<size_t>(total, 256);
     std::vector<char> staging(total, 0);
-    if (!p.windows.empty()) memcpy(staging.data() + o_win, p.windows.data(), p.windows.size() * sizeof(PpgWindow));
-    if (!p.blk_win.empty()) memcpy(staging.data() + o_blk, p.blk_win.data(), p.blk_win.size() * sizeof(int));
-    if (!p.items.empty()) memcpy(staging.data() + o_item, p.items.data(), p.items.size() * sizeof(AttnItem));
+    for (size_t gi = 0; gi < p.groups.size(); ++gi) {
+        const PlanGroup& grp = p.groups[gi];
+        memcpy(staging.data() + offs[gi].win, grp.windows.data(), grp.windows.size() * sizeof(PpgWindow));
+        memcpy(staging.data() + offs[gi].blk, grp.blk_win.data(), grp.blk_win.size() * sizeof(int));
+        memcpy(staging.data() + offs[gi].item, grp.items.data(), grp.items.size() * sizeof(AttnItem));
+    }
     // bound the cache: evict the least recently used plan
     if (e->plans.size() >= 64) {
         auto victim = e->plans.begin();
@@ -313,9 +382,12 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
     }
     HIP_OK(hipMalloc(&dp->buf, total));
     HIP_OK(hipMemcpy(dp->buf, staging.data(), total, hipMemcpyHostToDevice));
-    dp->win = reinterpret_cast<PpgWindow*>(static_cast<char*>(dp->buf) + o_win);
-    dp->blk_win = reinterpret_cast<int*>(static_cast<char*>(dp->buf) + o_blk);
-    dp->items = reinterpret_cast<AttnItem*>(static_cast<char*>(dp->buf) + o_item);
+    for (size_t gi = 0; gi < p.groups.size(); ++gi) {
+        char* base = static_cast<char*>(dp->buf);
+        p.groups[gi].d_win = reinterpret_cast<PpgWindow*>(base + offs[gi].win);
+        p.groups[gi].d_blk = reinterpret_cast<int*>(base + offs[gi].blk);
+        p.groups[gi].d_items = reinterpret_cast<AttnItem*>(base + offs[gi].item);
+    }
     dp->stamp = ++e->plan_stamp;
     *out = dp.get();
     e->plans.emplace(std::move(key), std::move(dp));
@@ -479,6 +551,16 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (const char* s = getenv("PPGS_AMD_FFN_AB")) e->ffn_variant = atoi(s);
+    if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < e->num_streams; ++i) {
+        hipStream_t st;
+        hipEvent_t ev;
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->side_streams.push_back(st);
+        e->ev_join.push_back(ev);
+    }
     if (getenv("PPGS_AMD_FFN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 1024));
         HIP_OK(hipMemset(e->ffn_dbg, 0, 1024));
@@ -559,7 +641,7 @@ int ppg_plan_windows(const PpgEngine* engine, int batch, int frames, const int64
     const int qt = ppg::attn_query_tile(engine ? engine->head_dim : 128);
     int rc = build_plan(chunk, overlap, maxpos, batch, frames, lengths, legacy_mode, qt, &plan);
     if (rc) return rc;
-    if (engine) plan.info.workspace_bytes = layout(engine, plan.info).total;
+    if (engine) finish_plan(engine, &plan);
     if (info) *info = plan.info;
     const int n = (int)plan.all.size();
     if (windows) for (int i = 0; i < n && i < max_windows; ++i) windows[i] = plan.all[i];
@@ -601,11 +683,21 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     }
     if (M == 0) return PPG_OK;
 
-    const Workspace ws = layout(e, plan.info);
-    if (!workspace || workspace_bytes < ws.total)
-        return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, ws.total);
+    if (!workspace || workspace_bytes < plan.info.workspace_bytes)
+        return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, plan.info.workspace_bytes);
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(PPG_EINVAL, "workspace not 256-byte aligned");
-    char* base = static_cast<char*>(workspace);
+
+#define LAUNCH_OK(expr, what)                                                        \
+    do {                                                                             \
+        hipError_t he_ = (expr);                                                     \
+        if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
+    } while (0)
+
+    // one independent pipeline per plan group, each on its own stream
+    auto run_group = [&](const PlanGroup& grp, hipStream_t s) -> int {
+    const int M = grp.tokens;
+    const Workspace ws = layout(e, grp.tokens, grp.vt_tokens);
+    char* base = static_cast<char*>(workspace) + grp.ws_offset;
     char* xw = base + ws.xw;
     float* X = reinterpret_cast<float*>(base + ws.x);
     char* Xb = e->sz == 2 ? base + ws.xb : nullptr;
@@ -614,12 +706,6 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     char* ao = base + ws.ao;
     char* hid = base + ws.hid;
     const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
-
-#define LAUNCH_OK(expr, what)                                                        \
-    do {                                                                             \
-        hipError_t he_ = (expr);                                                     \
-        if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
-    } while (0)
 
     const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);     // fused FFN
     // linear / conv kernels: measured best at C2 (two 256-register workgroups
@@ -639,12 +725,12 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         GatherArgs g{};
         g.feats = features; g.dtype = feature_dtype; g.C = c.input_channels; g.T = frames;
         g.overlap = c.chunk_overlap; g.xw = xw; g.Cp = e->Cp;
-        g.blk_win = dp->blk_win; g.win = dp->win; g.M = M;
+        g.blk_win = grp.d_blk; g.win = grp.d_win; g.M = M;
         LAUNCH_OK(ppg::launch_gather(prec, g, s), "gather");
     }
     auto base_args = [&]() {
         LinearArgs a{};
-        a.blk_win = dp->blk_win; a.win = dp->win; a.M = M; a.H = H;
+        a.blk_win = grp.d_blk; a.win = grp.d_win; a.M = M; a.H = H;
         a.X = X; a.Xb = Xb; a.v_start = INT_MAX; a.taps = 1;
         return a;
     };
@@ -675,8 +761,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
-            a.items = dp->items; a.win = dp->win; a.M = M;
-            LAUNCH_OK(ppg::launch_attn(prec, a, (int)plan.items.size(), c.heads, e->head_dim, s), "attention");
+            a.items = grp.d_items; a.win = grp.d_win; a.M = M;
+            LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
         {
             Timed t(e, PPG_K_OUTPROJ_LN, s);
@@ -718,6 +804,19 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
         LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, lnt_ln, a, 1, s), "out-conv+softmax");
     }
+    return PPG_OK;
+    };   // run_group
+
+    const size_t ngroups = plan.groups.size();
+    if (ngroups > 1) HIP_OK(hipEventRecord(e->ev_fork, s));
+    for (size_t gi = 1; gi < ngroups; ++gi) {
+        hipStream_t side = e->side_streams[gi - 1];
+        HIP_OK(hipStreamWaitEvent(side, e->ev_fork, 0));
+        if ((rc = run_group(plan.groups[gi], side))) return rc;
+        HIP_OK(hipEventRecord(e->ev_join[gi - 1], side));
+    }
+    if ((rc = run_group(plan.groups[0], s))) return rc;
+    for (size_t gi = 1; gi < ngroups; ++gi) HIP_OK(hipStreamWaitEvent(s, e->ev_join[gi - 1], 0));
 #undef LAUNCH_OK
     return PPG_OK;
 }

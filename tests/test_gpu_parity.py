@@ -253,11 +253,13 @@ def test_c2_full_size_statistics(golden):
     engine, _ = eng()
     alone = engine.encode(mel[5:6], [1000]).cpu()
     batch = engine.encode(mel, [1000] * 32).cpu()
-    assert (alone[0] - batch[5]).abs().max() < 1e-6
+    assert (alone[0] - batch[5]).abs().max() < 5e-6
     # permutation of batch rows permutes the output rows
     perm = torch.randperm(32, generator=gen)
     permuted = engine.encode(mel[perm.cuda()], [1000] * 32).cpu()
-    assert (permuted - batch[perm]).abs().max() < 1e-6
+    # (fp32 rounding only: the FFN walks the hidden chunks in a per-workgroup
+    # rotated order, so the summation order depends on the row's position)
+    assert (permuted - batch[perm]).abs().max() < 5e-6
 
 
 def test_files_to_files_roundtrip(tmp_path):
@@ -377,3 +379,19 @@ def test_large_ragged_batch_and_legacy_mode():
     assert np.abs(legacy - chunked).max() > 1e-4          # the two modes really differ
     with pytest.raises(ValueError):
         fp32.encode(torch.zeros(1, 80, 5000).half().cuda(), [5000], legacy_mode=True)
+
+
+def test_multi_stream_groups_agree(monkeypatch):
+    """PPGS_AMD_STREAMS=2: the batch is split into two window groups run as
+    independent pipelines on two HIP streams; same results as one stream."""
+    state = W.seeded_state_dict(seed=1234)
+    gen = torch.Generator().manual_seed(21)
+    lengths = [1000] * 30 + [730, 129]
+    feats = torch.randn(32, 80, 1000, generator=gen).half().cuda()
+    single = E.Engine(state, 0, 'fp32').encode(feats, lengths)
+    monkeypatch.setenv('PPGS_AMD_STREAMS', '2')
+    double_engine = E.Engine(state, 0, 'fp32')
+    _, info = E.plan_windows(32, 1000, lengths, engine=double_engine)
+    double = double_engine.encode(feats, lengths)
+    torch.cuda.synchronize()
+    assert (single - double).abs().max() < 5e-6
