@@ -764,8 +764,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   barrier #2 -> B waves load h(i) into registers
 // LDS: W1 x2 (64 KiB) | W2 x2 (64 KiB) | h hand-off (4 pairs) | b1.
 // ---------------------------------------------------------------------------
-template <class P, int NT, int NBH>
-__global__ __launch_bounds__(512, 2) void ffn_ab_kernel(FfnArgs a) {
+// PAIRS = 4: 8 waves, 2 per SIMD (<= 256 registers);  PAIRS = 6: 12 waves, 3 per
+// SIMD (<= 168 registers, 32-token pairs): 192 tokens per workgroup like the
+// single-wave kernel's 48-token tiles, i.e. one round of 214 workgroups at C2.
+template <class P, int NT, int NBH, int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS, PAIRS / 2) void ffn_ab_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = NBH * 16;
     constexpr int ROW1 = H * P::kBytes;
@@ -776,28 +779,28 @@ __global__ __launch_bounds__(512, 2) void ffn_ab_kernel(FfnArgs a) {
     constexpr int HG = ROW2 / 64;
     constexpr int HBUF_PAIR = HG * NT * 1024;        // one 1 KiB fragment per (kg, t)
     char* ldsh = smem + 131072;
-    char* ldsb1 = ldsh + 4 * HBUF_PAIR;
+    char* ldsb1 = ldsh + PAIRS * HBUF_PAIR;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
-    const int role = wave >> 2;                                    // 0 = A wave, 1 = B wave
-    const int pair = wave & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. 2*PAIRS-1
+    const int role = wave >= PAIRS ? 1 : 0;                        // 0 = A wave, 1 = B wave
+    const int pair = wave - role * PAIRS;
     const int idx = lane & 15;
     const int g = lane >> 4;
-    const int tok0 = (blockIdx.x * 4 + pair) * 16 * NT;
+    const int tok0 = (blockIdx.x * PAIRS + pair) * 16 * NT;
     const int NC = a.F / HC;
     const uint32_t lds0 = lds_addr(smem);
     char* hpair = ldsh + pair * HBUF_PAIR;
 
     const int rot = (blockIdx.x >> 3) % NC;
     auto hidden_chunk = [&](int c) { const int r = c + rot; return r >= NC ? r - NC : r; };
-    // all 8 waves share the DMA of a tile (4 pieces each)
+    // the first 8 waves share the DMA of a tile (4 pieces each)
     auto stage_w1 = [&](int c) {
-        stage_tile<HC, ROW1, 8>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
+        if (wave < 8) stage_tile<HC, ROW1, 8>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
     };
     auto stage_w2 = [&](int c) {
-        stage_tile<H, ROW2, 8>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
+        if (wave < 8) stage_tile<H, ROW2, 8>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
     };
     auto interval_dma = [&](int i) {
         if (i + 1 < NC) stage_w1(i + 1);
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void ffn_ab_kernel(FfnArgs a) {
     };
 
     stage_w1(0);
-    for (int i = tid; i < a.F / 4; i += 512)
+    for (int i = tid; i < a.F / 4; i += 128 * PAIRS)
         reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
 
     using LA = FragLayout<ROW1, HB>;
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void ffn_ab_kernel(FfnArgs a) {
                 f32x4 hacc[HB][NT];
                 uint32_t fba[LA::VAR];
                 LA::bases(lds0 + (i & 1) * 32768, idx, g, fba);
-                lds_stream<LA, XG * HB, 6>(fba, [&](auto ic, const u32x4& wf) {
+                lds_stream<LA, XG * HB, (PAIRS > 4 ? 4 : 6)>(fba, [&](auto ic, const u32x4& wf) {
                     constexpr int s_ = decltype(ic)::value;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void ffn_ab_kernel(FfnArgs a) {
                 // interval.  Its first K-group is loaded before this interval's
                 // DMA is issued (an ordinary LDS load behind an in-flight LDS DMA
                 // makes hipcc drain the DMA); later groups by asm reads.
-                constexpr int DB = NT >= 3 ? 4 : 6;
+                constexpr int DB = (NT >= 3 || PAIRS > 4) ? 4 : 6;
                 u32x4 hf[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -1160,28 +1163,31 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <class P, int NT, int NBH>
+template <class P, int NT, int NBH, int PAIRS>
 hipError_t launch_ffn_ab_t(const FfnArgs& a, hipStream_t s) {
-    const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
-    auto kern = ffn_ab_kernel<P, NT, NBH>;
-    const size_t lds = 131072 + 4 * (size_t)((NBH * 16 * P::kBytes >= 1024 && NBH == 32 ? 1 : 2) * NT * 1024) + (size_t)a.F * 4;
+    const int blocks = (a.M + 16 * NT * PAIRS - 1) / (16 * NT * PAIRS);
+    auto kern = ffn_ab_kernel<P, NT, NBH, PAIRS>;
+    constexpr int HG = (32768 / (NBH * 16 * P::kBytes)) * P::kBytes / 64;      // K-groups of phase B per chunk
+    const size_t lds = 131072 + (size_t)PAIRS * HG * NT * 1024 + (size_t)a.F * 4;
+    if (lds > 163840) return hipErrorInvalidValue;
     static size_t configured = 0;
     if (configured < lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(128 * PAIRS), lds, s, a);
     return hipGetLastError();
 }
 
 template <class P>
 hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
     if (a.variant == 1 && a.H == 256) {
-        if (nt == 1) return launch_ffn_ab_t<P, 1, 16>(a, s);
-        if (nt == 3) return launch_ffn_ab_t<P, 3, 16>(a, s);
-        return launch_ffn_ab_t<P, 2, 16>(a, s);
+        if (nt == 1) return launch_ffn_ab_t<P, 1, 16, 4>(a, s);
+        if (nt == 3) return launch_ffn_ab_t<P, 3, 16, 4>(a, s);
+        return launch_ffn_ab_t<P, 2, 16, 4>(a, s);
     }
+    if (a.variant == 2 && a.H == 256) return launch_ffn_ab_t<P, 2, 16, 6>(a, s);
     if (a.H == 256) {
         if (nt == 1) return launch_ffn_t<P, 1, 16>(a, s);
         if (nt == 3) return launch_ffn_t<P, 3, 16>(a, s);
