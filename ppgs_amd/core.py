@@ -213,11 +213,12 @@ def from_dataloader(dataloader, output_files,
     try:
         for audios, lengths, audio_files in dataloader:
             frame_lengths = lengths // config.HOPSIZE
-            if representation != 'mel':
+            if representation not in ('mel', 'w2v2fb'):
                 raise ValueError(
-                    f'from_dataloader supports the mel representation, '
-                    f'got {representation!r}')
-            features = preprocess.mel.from_audios(audios, lengths, gpu=gpu)
+                    f'from_dataloader supports the mel and w2v2fb '
+                    f'representations, got {representation!r}')
+            features = getattr(preprocess, representation).from_audios(
+                audios, lengths, gpu=gpu)
             result = from_features(
                 features=features, lengths=frame_lengths,
                 representation=representation, checkpoint=checkpoint, gpu=gpu,

@@ -2,7 +2,7 @@
 import torch
 
 from .. import config
-from . import mel, spectrogram
+from . import mel, spectrogram, w2v2fb
 
 
 def from_audio(audio, representation=config.REPRESENTATION,
@@ -13,11 +13,12 @@ def from_audio(audio, representation=config.REPRESENTATION,
     audio = core.resample(audio, sample_rate)
     if representation is None:
         representation = config.REPRESENTATION
-    if representation != 'mel':
+    if representation not in ('mel', 'w2v2fb'):
         raise ValueError(
             f'representation {representation!r} has no audio frontend here; '
             "compute the features yourself and call from_features")
-    features = mel.from_audio(audio, sample_rate=config.SAMPLE_RATE, gpu=gpu)
+    frontend = mel if representation == 'mel' else w2v2fb
+    features = frontend.from_audio(audio, sample_rate=config.SAMPLE_RATE, gpu=gpu)
     if features.dim() == 2:
         features = features[None]
     return features

@@ -395,3 +395,38 @@ def test_multi_stream_groups_agree(monkeypatch):
     double = double_engine.encode(feats, lengths)
     torch.cuda.synchronize()
     assert (single - double).abs().max() < 5e-6
+
+
+def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
+    """configs[2]: w2v2fb representation.  The wav2vec2 body is the
+    reference's third-party HF model (seeded random init offline) run on the
+    GPU by PyTorch-ROCm; its latents match the same model on the CPU, and the
+    768-channel / hidden-512 PPG network on top runs in the HIP engine and
+    matches the oracle on the same latents."""
+    monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
+    import transformers
+    from ppgs_amd.preprocess import w2v2fb
+    w2v2fb._models.clear()
+    gen = torch.Generator().manual_seed(2)
+    audio = 0.1 * torch.randn(2, 1, 16000, generator=gen)
+    lengths = torch.tensor([16000, 12000])
+    audio[1, :, 12000:] = 0
+    feats = w2v2fb.from_audios(audio, lengths, gpu=0)
+    assert feats.shape == (2, 768, 100) and feats.dtype == torch.float16 and feats.is_cuda
+    # the same third-party model on the CPU (what the reference would run)
+    torch.manual_seed(7)
+    cpu_model = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config()).eval()
+    with torch.no_grad():
+        padded = torch.nn.functional.pad(audio, (40, 40)).squeeze(1)
+        positions = torch.arange(16000 + 80) - 80
+        mask = (positions[None] < lengths[:, None]).long()
+        ref = cpu_model(padded, mask).last_hidden_state.transpose(1, 2)
+        ref = torch.nn.functional.interpolate(ref, size=100, mode='nearest').half()
+    assert (feats.cpu().float() - ref.float()).abs().max() < 2e-2
+    state = W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512)
+    engine = E.Engine(state, 0, 'fp32')
+    frames = lengths // 160
+    ppg = engine.encode(feats, frames).cpu().numpy()
+    oracle = O.from_features(state, feats.cpu(), frames).numpy()
+    assert np.abs(ppg - oracle).max() < FP32_TOL
+    w2v2fb._models.clear()
