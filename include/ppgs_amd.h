@@ -207,6 +207,32 @@ int ppg_engine_profile_reset(PpgEngine* engine);
 int ppg_frontend_profile(int device, int enable);
 int ppg_frontend_profile_read(int device, double* total_ms, int64_t* launches);
 
+/*
+ * Host-side ingest / output stage of the file pipeline (no GPU involved).
+ *
+ * ppg_wav_read_batch: decode `count` RIFF/WAVE files (PCM 8/16/24/32-bit,
+ * IEEE float 32/64, first channel) into rows of one fp32 batch buffer
+ * dst[count][row_stride], zero-padded behind each file's samples, `threads`
+ * at a time -- replaces torchaudio.load (ppgs/load.py:17-30) + the zero-pad
+ * Collate (ppgs/data/collate.py:20-27) of the reference's DataLoader workers.
+ * samples_out / rates_out receive each file's sample count and sample rate
+ * (files not at 16 kHz must be resampled by the caller).
+ *
+ * ppg_pt_write_batch: write item i as a torch.load-able ".pt" holding the
+ * contiguous fp32 tensor src[i][0:rows][0:cols[i]] -- replaces the spawn Pool
+ * of save_masked / torch.save workers (ppgs/preprocess/core.py:219-221,
+ * ppgs/core.py:358-378).
+ */
+const char* ppg_io_last_error(void);
+int ppg_wav_info(const char* path, int64_t* samples, int32_t* sample_rate,
+                 int32_t* channels);
+int ppg_wav_read_batch(const char* const* paths, int count, float* dst,
+                       int64_t row_stride, int64_t max_samples,
+                       int64_t* samples_out, int32_t* rates_out, int threads);
+int ppg_pt_write_batch(const char* const* paths, int count, const float* src,
+                       int64_t item_stride, int rows, int64_t row_stride,
+                       const int64_t* cols, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,14 +169,18 @@ class loader:
     def __init__(self, audio_files, num_workers=1,
                  max_frames=config.MAX_INFERENCE_FRAMES, mode='sorted'):
         self.files = list(audio_files)
-        frames = []
+        frames, self.samples, self.rates = [], [], []
         for file in self.files:
             samples, rate = load.info(file)
             frames.append(data.frames_of(samples, rate))
+            self.samples.append(samples)
+            self.rates.append(rate)
         budget = max_frames
         keep = data.filter_lengths(frames, budget, self.files)
         self.files = [self.files[i] for i in keep]
         self.frames = [frames[i] for i in keep]
+        self.samples = [self.samples[i] for i in keep]
+        self.rates = [self.rates[i] for i in keep]
         if math.isinf(budget):
             budget = max(DEFAULT_BATCH_FRAMES, max(self.frames, default=0))
         self.batches = data.pack_batches(self.frames, budget, mode=mode)
@@ -186,19 +190,29 @@ class loader:
     def __len__(self):
         return len(self.batches)
 
+    def _load(self, indices):
+        """One padded batch.  16 kHz WAV files are decoded by the native
+        multi-threaded reader straight into a pinned (B, 1, maxlen) buffer;
+        anything else goes through load.audio (resampling) + collate."""
+        files = [self.files[i] for i in indices]
+        if all(self.rates[i] == config.SAMPLE_RATE for i in indices):
+            longest = max(self.samples[i] for i in indices)
+            padded, lengths, _ = engine.wav_read_batch(
+                files, longest, threads=self.num_workers)
+            return padded, lengths, tuple(files)
+        audios = [load.audio(file)[:1] for file in files]
+        padded, lengths = data.collate(audios)
+        return padded, lengths, tuple(files)
+
     def __iter__(self):
-        with ThreadPoolExecutor(self.num_workers) as pool:
+        # one batch decoded ahead of the consumer (the native reader and the
+        # Python fallback both release the GIL while reading)
+        with ThreadPoolExecutor(1) as pool:
             pending = None
             for batch in self.batches + [None]:
-                upcoming = None
-                if batch is not None:
-                    upcoming = (batch, [
-                        pool.submit(load.audio, self.files[i]) for i in batch])
+                upcoming = pool.submit(self._load, batch) if batch is not None else None
                 if pending is not None:
-                    indices, futures = pending
-                    audios = [f.result()[:1] for f in futures]
-                    padded, lengths = data.collate(audios)
-                    yield padded, lengths, tuple(self.files[i] for i in indices)
+                    yield pending.result()
                 pending = upcoming
 
 
@@ -207,33 +221,77 @@ def from_dataloader(dataloader, output_files,
                     save_workers=1, gpu=None, legacy_mode=False):
     """Infer ppgs from a dataloader yielding (audio, length, filename) batches
     (reference ppgs/core.py:280-391): frontend on the padded batch, forward,
-    then each item truncated to length // 160 frames and saved."""
-    pool = ThreadPoolExecutor(save_workers) if save_workers > 0 else None
+    then each item truncated to length // 160 frames and saved.
+
+    Batches are software-pipelined over two HIP streams: while batch i runs
+    its kernels, batch i+1's audio goes host -> device from pinned memory and
+    batch i-1's posteriors come back into pinned memory and are handed to the
+    writer threads (the reference does the three steps back to back and
+    blocks on ``result.cpu()``, core.py:363).
+    """
+    if representation not in ('mel', 'w2v2fb'):
+        raise ValueError(
+            f'from_dataloader supports the mel and w2v2fb representations, '
+            f'got {representation!r}')
+    device = device_for(gpu)
+    frontend = getattr(preprocess, representation)
+    pool = ThreadPoolExecutor(2) if save_workers > 0 else None
     pending = []
+
+    class Slot:
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device)
+            self.done = torch.cuda.Event()
+            self.job = None
+
+    slots = [Slot(), Slot()]
+
+    def retire(slot):
+        """Wait for the slot's batch, hand its rows to the writers."""
+        if slot.job is None:
+            return
+        host, filenames, frame_lengths, keep = slot.job
+        slot.done.synchronize()
+        slot.job = None
+        # the native writer emits torch.load-able (40, length) files, several
+        # threads per batch, off the main thread
+        if pool is not None:
+            pending.append(pool.submit(
+                engine.pt_write_batch, filenames, host, frame_lengths,
+                max(save_workers, 1)))
+        else:
+            engine.pt_write_batch(filenames, host, frame_lengths, 1)
+        # back-pressure on the save queue (reference core.py:364-365)
+        while len(pending) > 8:
+            pending.pop(0).result()
+
     try:
-        for audios, lengths, audio_files in dataloader:
+        for index, (audios, lengths, audio_files) in enumerate(dataloader):
+            slot = slots[index % 2]
+            retire(slot)                      # its buffers are free again
             frame_lengths = lengths // config.HOPSIZE
-            if representation not in ('mel', 'w2v2fb'):
-                raise ValueError(
-                    f'from_dataloader supports the mel and w2v2fb '
-                    f'representations, got {representation!r}')
-            features = getattr(preprocess, representation).from_audios(
-                audios, lengths, gpu=gpu)
-            result = from_features(
-                features=features, lengths=frame_lengths,
-                representation=representation, checkpoint=checkpoint, gpu=gpu,
-                legacy_mode=legacy_mode).cpu()
             filenames = [output_files[file] for file in audio_files]
-            for ppg, filename, length in zip(result, filenames, frame_lengths):
-                if pool is not None:
-                    pending.append(pool.submit(
-                        preprocess.save_masked, ppg, filename, int(length)))
-                else:
-                    preprocess.save_masked(ppg, filename, int(length))
-            # back-pressure on the save queue (reference core.py:364-365)
-            while len(pending) > 100:
-                pending.pop(0).result()
+            staged = audios if audios.is_pinned() else audios.pin_memory()
+            with torch.cuda.stream(slot.stream):
+                on_device = staged.to(device, non_blocking=True)
+                features = frontend.from_audios(on_device, lengths, gpu=device.index)
+                result = from_features(
+                    features=features, lengths=frame_lengths,
+                    representation=representation, checkpoint=checkpoint,
+                    gpu=device.index, legacy_mode=legacy_mode)
+                host = torch.empty(
+                    result.shape, dtype=result.dtype, pin_memory=True)
+                host.copy_(result, non_blocking=True)
+                slot.done.record(slot.stream)
+            # keep the device tensors alive until the stream has used them
+            slot.job = (host, filenames, frame_lengths.tolist(),
+                        (staged, on_device, features, result))
+        for slot in slots:
+            retire(slot)
     finally:
+        for slot in slots:
+            if slot.job is not None:
+                slot.done.synchronize()
         for future in pending:
             future.result()
         if pool is not None:

@@ -125,3 +125,32 @@ def from_audios_sharded(audios, compute=None, gpu=None, max_frames=32000,
         for index, ppg in zip(shard, gathered[r]):
             ordered[index] = ppg
     return ordered
+
+
+def from_files_to_files_sharded(audio_files, output_files, runner=None, **kwargs):
+    """File-to-file inference with every rank: the file list is LPT-sharded
+    by chunk-aware FLOP cost (lengths from the WAV headers), rank r runs
+    ``ppgs_amd.from_files_to_files`` on its shard and writes its own outputs.
+    No collective is needed (reference ppgs/core.py:207-272 is single
+    device); a barrier at the end makes completion global.  ``runner(files,
+    outputs)`` replaces the per-rank call (tests)."""
+    from . import load
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    frames = []
+    for file in audio_files:
+        samples, rate = load.info(file)
+        frames.append(data.frames_of(samples, rate))
+    shards = shard_lpt([data.flops(max(f, 1)) for f in frames], world_size)
+    mine = shards[rank]
+    files = [audio_files[i] for i in mine]
+    outputs = [output_files[i] for i in mine]
+    if files:
+        if runner is not None:
+            runner(files, outputs)
+        else:
+            from . import core
+            core.from_files_to_files(files, outputs, **kwargs)
+    if dist.is_initialized():
+        dist.barrier()
+    return mine

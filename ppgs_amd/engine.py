@@ -90,6 +90,17 @@ SYMBOLS = {
     'ppg_frontend_profile': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     'ppg_frontend_profile_read': (ctypes.c_int, [
         ctypes.c_int, ctypes.POINTER(ctypes.c_double), _I64P]),
+    'ppg_io_last_error': (ctypes.c_char_p, []),
+    'ppg_wav_info': (ctypes.c_int, [
+        ctypes.c_char_p, _I64P, ctypes.POINTER(ctypes.c_int32),
+        ctypes.POINTER(ctypes.c_int32)]),
+    'ppg_wav_read_batch': (ctypes.c_int, [
+        ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_int64, _I64P,
+        ctypes.POINTER(ctypes.c_int32), ctypes.c_int]),
+    'ppg_pt_write_batch': (ctypes.c_int, [
+        ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_int64, _I64P, ctypes.c_int]),
 }
 
 
@@ -213,7 +224,7 @@ class Engine:
             ctypes.byref(cfg), ctypes.byref(wts), device, ctypes.byref(handle)))
         self._handle = handle
         self._lib = lib
-        self._workspace = None
+        self._workspaces = {}         # one scratch buffer per HIP stream in use
 
     def __del__(self):
         handle = getattr(self, '_handle', None)
@@ -248,18 +259,22 @@ class Engine:
         _check(self._lib.ppg_workspace_bytes(
             self._handle, batch, frames, arr, int(legacy_mode),
             ctypes.byref(size)))
-        if self._workspace is None or self._workspace.numel() < size.value:
-            self._workspace = torch.empty(
-                max(size.value, 256), dtype=torch.uint8, device=self.device)
-        out = torch.empty(
-            (batch, self.output_channels, frames), dtype=torch.float32,
-            device=self.device)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
+            # encodes issued on different streams may overlap: each stream
+            # gets its own scratch buffer (grow-only, reused call to call)
+            workspace = self._workspaces.get(stream)
+            if workspace is None or workspace.numel() < size.value:
+                workspace = torch.empty(
+                    max(size.value, 256), dtype=torch.uint8, device=self.device)
+                self._workspaces[stream] = workspace
+            out = torch.empty(
+                (batch, self.output_channels, frames), dtype=torch.float32,
+                device=self.device)
             _check(self._lib.ppg_encode(
                 self._handle, features.data_ptr(), dtype, arr, batch, frames,
                 int(softmax), int(legacy_mode), out.data_ptr(),
-                self._workspace.data_ptr(), self._workspace.numel(), stream))
+                workspace.data_ptr(), workspace.numel(), stream))
         return out
 
     # -- per-kernel HIP-event timing (bench.py roofline leg) ----------------
@@ -324,3 +339,56 @@ def frontend_profile_read(device):
     _check(library().ppg_frontend_profile_read(
         device, ctypes.byref(total), ctypes.byref(count)))
     return total.value, count.value
+
+
+###############################################################################
+# Native file ingest / output (host only)
+###############################################################################
+
+
+def _paths_array(paths):
+    encoded = [os.fsencode(os.fspath(p)) for p in paths]
+    return (ctypes.c_char_p * len(encoded))(*encoded)
+
+
+def _check_io(code):
+    if code < 0:
+        raise ValueError('ppgs_amd: ' + library().ppg_io_last_error().decode())
+
+
+def wav_info(path):
+    """(samples per channel, sample rate, channels) from the RIFF header."""
+    samples, rate, channels = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+    _check_io(library().ppg_wav_info(
+        os.fsencode(os.fspath(path)), ctypes.byref(samples), ctypes.byref(rate),
+        ctypes.byref(channels)))
+    return samples.value, rate.value, channels.value
+
+
+def wav_read_batch(paths, max_samples, threads=4, pin_memory=None):
+    """Decode WAV files into one zero-padded (B, 1, max_samples) fp32 tensor
+    (pinned when a GPU is present) -> (tensor, samples (B,), rates list)."""
+    count = len(paths)
+    if pin_memory is None:
+        pin_memory = torch.cuda.is_available()
+    batch = torch.empty((count, 1, max_samples), dtype=torch.float32,
+                        pin_memory=pin_memory)
+    samples = (ctypes.c_int64 * count)()
+    rates = (ctypes.c_int32 * count)()
+    _check_io(library().ppg_wav_read_batch(
+        _paths_array(paths), count, batch.data_ptr(), max_samples, max_samples,
+        samples, rates, int(threads)))
+    return batch, torch.tensor(list(samples), dtype=torch.long), list(rates)
+
+
+def pt_write_batch(paths, tensor, lengths, threads=4):
+    """Write tensor[i, :, :lengths[i]] (fp32, CPU, (B, rows, T) contiguous) as
+    torch.load-able .pt files."""
+    if tensor.is_cuda or tensor.dtype != torch.float32 or tensor.dim() != 3:
+        raise ValueError('pt_write_batch expects a CPU fp32 (B, rows, T) tensor')
+    tensor = tensor.contiguous()
+    count, rows, frames = tensor.shape
+    cols = (ctypes.c_int64 * count)(*[int(v) for v in lengths])
+    _check_io(library().ppg_pt_write_batch(
+        _paths_array(paths), count, tensor.data_ptr(), rows * frames, rows,
+        frames, cols, int(threads)))

@@ -41,26 +41,9 @@ def audio(file):
 def info(file):
     """(num_samples, sample_rate) from the RIFF header, without decoding
     (the reference uses torchaudio.info, ppgs/data/dataset.py:187)."""
-    import struct
-    with open(os.fspath(file), 'rb') as handle:
-        riff, _, wav = struct.unpack('<4sI4s', handle.read(12))
-        if riff != b'RIFF' or wav != b'WAVE':
-            raise ValueError(f'{file} is not a RIFF/WAVE file')
-        rate = block_align = None
-        while True:
-            header = handle.read(8)
-            if len(header) < 8:
-                raise ValueError(f'{file} has no data chunk')
-            tag, size = struct.unpack('<4sI', header)
-            if tag == b'fmt ':
-                fmt = handle.read(size + (size & 1))
-                _, _, rate, _, block_align = struct.unpack('<HHIIH', fmt[:14])
-            elif tag == b'data':
-                if not block_align:
-                    raise ValueError(f'{file}: data chunk before fmt chunk')
-                return size // block_align, rate
-            else:
-                handle.seek(size + (size & 1), os.SEEK_CUR)
+    from . import engine
+    samples, rate, _ = engine.wav_info(file)
+    return samples, rate
 
 
 def state_dict(checkpoint=None, representation=None):

@@ -67,3 +67,35 @@ def test_two_rank_sharded_inference_matches_single_process(tmp_path):
                 ppg = got['out'][index]
                 assert ppg.shape == (40, lengths[index])
                 assert np.abs(ppg.numpy() - ref[row, :, :lengths[index]].numpy()).max() < 1e-6
+
+
+def files_worker(rank, port, root, count):
+    os.environ.update(
+        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+        WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    from ppgs_amd import distributed
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    files = [os.path.join(root, f'{i}.wav') for i in range(count)]
+    outs = [os.path.join(root, f'{i}.pt') for i in range(count)]
+
+    def runner(mine, outputs):          # stands in for the GPU run of the shard
+        for src, dst in zip(mine, outputs):
+            torch.save(torch.tensor([rank]), dst)
+
+    distributed.from_files_to_files_sharded(files, outs, runner=runner)
+    dist.destroy_process_group()
+
+
+def test_two_rank_file_sharding(tmp_path):
+    from scipy.io import wavfile
+    rng = np.random.default_rng(0)
+    lengths = [16000 * k for k in (1, 7, 3, 2, 9, 4)]
+    for i, n in enumerate(lengths):
+        wavfile.write(tmp_path / f'{i}.wav', 16000, np.zeros(n, np.float32))
+    mp.spawn(files_worker, args=(free_port(), str(tmp_path), len(lengths)), nprocs=WORLD, join=True)
+    owners = [int(torch.load(tmp_path / f'{i}.pt')[0]) for i in range(len(lengths))]
+    assert set(owners) == {0, 1}                      # every file written exactly once, both ranks used
+    from ppgs_amd import data, distributed
+    shards = distributed.shard_lpt([data.flops(n // 160) for n in lengths], WORLD)
+    assert [owners[i] for i in shards[0]] == [0] * len(shards[0])
+    assert [owners[i] for i in shards[1]] == [1] * len(shards[1])

@@ -1,0 +1,89 @@
+"""Native ingest / output stage (host only): WAV batch decode against the
+scipy-based loader, .pt writer against torch.load."""
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from ppgs_amd import engine as E
+from ppgs_amd import load
+
+
+@pytest.fixture()
+def wavs(tmp_path):
+    rng = np.random.default_rng(0)
+    x = (0.1 * rng.standard_normal(4321)).astype(np.float32)
+    files = {
+        'f32': x, 'f64': x.astype(np.float64),
+        'i16': (x * 32768).astype(np.int16), 'i32': (x * 2 ** 31).astype(np.int32),
+        'u8': ((x * 128) + 128).astype(np.uint8), 'stereo': np.stack([x, -x], 1),
+    }
+    paths = []
+    for name, samples in files.items():
+        path = tmp_path / f'{name}.wav'
+        wavfile.write(path, 16000, samples)
+        paths.append(path)
+    return paths
+
+
+def test_wav_batch_matches_python_loader(wavs):
+    batch, lengths, rates = E.wav_read_batch(wavs, 5000, threads=3, pin_memory=False)
+    assert batch.shape == (len(wavs), 1, 5000)
+    assert lengths.tolist() == [4321] * len(wavs) and rates == [16000] * len(wavs)
+    for row, path in zip(batch, wavs):
+        reference = load.audio(path)[0]
+        assert torch.equal(row[0, :4321], reference), path        # bit-identical decode
+        assert row[0, 4321:].abs().max() == 0                      # collate zero padding
+    assert E.wav_info(wavs[-1]) == (4321, 16000, 2)
+    # truncation to max_samples
+    batch, lengths, _ = E.wav_read_batch(wavs[:1], 1000, threads=1, pin_memory=False)
+    assert torch.equal(batch[0, 0], load.audio(wavs[0])[0, :1000]) and lengths.tolist() == [4321]
+
+
+def test_wav_errors(tmp_path):
+    bad = tmp_path / 'bad.wav'
+    bad.write_bytes(b'not a wave file at all')
+    with pytest.raises(ValueError, match='RIFF'):
+        E.wav_info(bad)
+    with pytest.raises(ValueError, match='cannot open'):
+        E.wav_read_batch([tmp_path / 'missing.wav'], 100, pin_memory=False)
+
+
+def test_pt_writer_is_torch_loadable(tmp_path):
+    gen = torch.Generator().manual_seed(1)
+    tensor = torch.randn(6, 40, 257, generator=gen)
+    lengths = [257, 256, 1, 0, 100, 17]
+    paths = [tmp_path / f'{i}.pt' for i in range(6)]
+    E.pt_write_batch(paths, tensor, lengths, threads=4)
+    for path, row, length in zip(paths, tensor, lengths):
+        loaded = torch.load(path, weights_only=True)
+        assert loaded.dtype == torch.float32 and loaded.shape == (40, length)
+        assert loaded.is_contiguous() and torch.equal(loaded, row[:, :length])
+        # same content as the reference's save_masked (preprocess/core.py:219-221)
+        torch.save(row[..., :length].clone(), tmp_path / 'ref.pt')
+        assert torch.equal(torch.load(tmp_path / 'ref.pt'), loaded)
+    with pytest.raises(ValueError):
+        E.pt_write_batch(paths[:1], tensor[:1], [300])
+
+
+def test_loader_batches_native_and_fallback(tmp_path):
+    """The loader decodes 16 kHz files natively and falls back to the Python
+    path (resampling) for other rates; both give the collate semantics."""
+    import ppgs_amd
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check of the loader (pinned memory not needed)')
+    rng = np.random.default_rng(3)
+    files = []
+    for i, (n, rate) in enumerate(((3200, 16000), (1600, 16000), (2400, 8000))):
+        path = tmp_path / f'{i}.wav'
+        wavfile.write(path, rate, (0.1 * rng.standard_normal(n)).astype(np.float32))
+        files.append(path)
+    batches = list(ppgs_amd.core.loader(files, num_workers=2, max_frames=1000))
+    seen = {f for _, _, names in batches for f in names}
+    assert seen == set(files)
+    for padded, lengths, names in batches:
+        assert padded.shape[0] == len(names) and padded.shape[2] == int(lengths.max())
+        for row, length, name in zip(padded, lengths, names):
+            reference = load.audio(name)[0]
+            assert torch.allclose(row[0, :length], reference[:length])
+            assert row[0, length:].abs().sum() == 0
