@@ -159,6 +159,8 @@ struct FfnArgs {
     int M;
     unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
     int variant;              // 0: one wave per SIMD (ffn_kernel); 1: A/B wave pairs (ffn_ab_kernel)
+    float* partial;           // split-hidden mode: [splits][M][H] fp32 partial sums, else null
+    int splits;
 };
 
 struct AttnItem {

@@ -179,7 +179,8 @@ struct DevPlan {
 };
 
 struct Workspace {
-    size_t xw, x, xb, qk, vt, ao, hid, total;
+    size_t xw, x, xb, qk, vt, ao, hid, part, total;
+    int ffn_nt, ffn_splits;
     int vt_ld, qk_rows;
 };
 
@@ -200,6 +201,7 @@ struct PpgEngine {
     int lin_nt = 0;       // same for the linear/conv kernels
     int num_cus = 256;
     bool ffn_fused = true;
+    bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int ffn_variant = 0;
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
                             // but kernels of the two halves then overlap and per-kernel timings blur)
@@ -295,6 +297,31 @@ int choose_nt(const PpgEngine* e, int M, int max_nt) {
     return best;
 }
 
+// Fused-FFN tiling for a group of `M` token rows: tokens per wave (16*nt) and,
+// when the tiles cannot fill the CUs, how many workgroups share one tile by
+// splitting the hidden chunks between them (partial sums + a reduce/LN pass).
+// A workgroup streams all of W1/W2 through its CU whatever its tile size, so
+// few large tiles x several hidden splits beats many small tiles.
+void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) {
+    const int max_nt = (e->cfg.precision == PPG_PRECISION_BF16 && e->cfg.hidden_channels == 256) ? 3
+                       : (e->cfg.hidden_channels == 256 ? 2 : 1);
+    int nt = choose_nt(e, M, max_nt);
+    int splits = 1;
+    const int chunks = e->cfg.ffn_channels / (32768 / (e->cfg.hidden_channels * e->sz));
+    if (e->ffn_split && e->ffn_fused && e->ffn_variant == 0 && e->ffn_nt == 0) {
+        const int tiles_max_nt = (M + 64 * max_nt - 1) / (64 * max_nt);
+        // only when the tiles would leave 7/8 of the chip idle: the partial-sum
+        // round trip costs about as much as it saves above that (measured: 64 x 160
+        // frames, 54 tiles: 500 us/step unsplit vs 576 us split)
+        if (tiles_max_nt * 8 <= e->num_cus) {
+            nt = max_nt;
+            while (splits * 2 <= chunks / 2 && tiles_max_nt * splits * 2 <= e->num_cus) splits *= 2;
+        }
+    }
+    *nt_out = nt;
+    *splits_out = splits;
+}
+
 Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
     Workspace w{};
     const size_t M = tokens;
@@ -310,6 +337,8 @@ Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
     w.vt = take((size_t)H * w.vt_ld * e->sz);
     w.ao = take(M * H * e->sz);
     w.hid = take(e->ffn_fused ? 0 : M * e->cfg.ffn_channels * e->sz);
+    choose_ffn_tiling(e, tokens, &w.ffn_nt, &w.ffn_splits);
+    w.part = take(w.ffn_splits > 1 ? (size_t)w.ffn_splits * M * H * 4 : 0);
     w.total = off;
     return w;
 }
@@ -550,6 +579,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
+    if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
     if (const char* s = getenv("PPGS_AMD_FFN_AB")) e->ffn_variant = atoi(s);
     if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -707,7 +737,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     char* hid = base + ws.hid;
     const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
 
-    const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);     // fused FFN
+    const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);     // linear / conv kernels
     // linear / conv kernels: measured best at C2 (two 256-register workgroups
     // per CU): 32-token waves for the wide projections, 16-token waves where
     // the epilogue dominates (LayerNorm, softmax scatter)
@@ -778,7 +808,9 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 FfnArgs a{};
                 a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
                 a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr; a.variant = e->ffn_variant;
-                LAUNCH_OK(ppg::launch_ffn(prec, a, H == 256 ? nt : 1, s), "ffn");
+                a.splits = ws.ffn_splits;
+                a.partial = ws.ffn_splits > 1 ? reinterpret_cast<float*>(base + ws.part) : nullptr;
+                LAUNCH_OK(ppg::launch_ffn(prec, a, ws.ffn_nt, s), "ffn");
             } else {
                 LinearArgs a = base_args();
                 a.act = act_x; a.lda_bytes = H * e->sz;

@@ -594,7 +594,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int idx = lane & 15;
     const int g = lane >> 4;
     const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
-    const int NC = a.F / HC;
+    // gridDim.y > 1: split-hidden mode for token counts that cannot fill the
+    // chip -- this workgroup sums only its 1/gridDim.y of the hidden chunks
+    // and writes fp32 partial sums; ffn_reduce_ln_kernel finishes the layer.
+    const int NC = a.F / HC / gridDim.y;
+    const int c_base = blockIdx.y * NC;
 
     // LDS: W1 tiles at 0 / 32 KiB, W2 tiles at 64 / 96 KiB, b1 at 128 KiB
     // The sum over hidden chunks is order-free: workgroup b walks the chunks
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // do not all pull the same 64 KiB of weights through the same L2 lines at
     // the same moment.
     const int rot = (blockIdx.x >> 3) % NC;
-    auto hidden_chunk = [&](int c) { const int r = c + rot; return r >= NC ? r - NC : r; };
+    auto hidden_chunk = [&](int c) { const int r = c + rot; return c_base + (r >= NC ? r - NC : r); };
     auto stage_w1 = [&](int c) {
         stage_tile<HC, ROW1, 4>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
     };
@@ -740,7 +744,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int t = 0; t < NT; ++t) h0[hb][t] = h1[hb][t];
     }
 
+    if (a.partial != nullptr) {
+        // split-hidden: raw partial sums, [split][token][feature] fp32
+        float* part = a.partial + (size_t)blockIdx.y * a.M * H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int m = tok0 + 16 * t + idx;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int nb = 0; nb < NBH; ++nb)
+                *reinterpret_cast<float4*>(part + (size_t)m * H + nb * 16 + 4 * g) =
+                    make_float4(yacc[nb][t][0], yacc[nb][t][1], yacc[nb][t][2], yacc[nb][t][3]);
+        }
+        return;
+    }
     resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
+}
+
+// Second half of the split-hidden FFN: X <- LN(X + b2 + sum_s partial[s]).
+// One wave per token row (64 lanes x float4 = 256 features; hidden 512 in two
+// steps), HBM-bound elementwise.
+template <class P>
+__global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int splits) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int H = a.H;
+    float4 v[2];
+    float sum = 0.f;
+    for (int h = 0; h < H / 256; ++h) {
+        const int n = h * 256 + lane * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(a.b2 + n);
+        const float4 xv = *reinterpret_cast<const float4*>(a.X + (size_t)m * H + n);
+        float4 acc = make_float4(bv.x + xv.x, bv.y + xv.y, bv.z + xv.z, bv.w + xv.w);
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)sidx * a.M + m) * H + n);
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        v[h] = acc;
+        sum += (acc.x + acc.y) + (acc.z + acc.w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)H;
+    float sq = 0.f;
+    for (int h = 0; h < H / 256; ++h) {
+        const float d0 = v[h].x - mean, d1 = v[h].y - mean, d2 = v[h].z - mean, d3 = v[h].w - mean;
+        sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / (float)H + kLnEps);
+    for (int h = 0; h < H / 256; ++h) {
+        const int n = h * 256 + lane * 4;
+        const float4 gv = *reinterpret_cast<const float4*>(a.gamma + n);
+        const float4 ev = *reinterpret_cast<const float4*>(a.beta + n);
+        const float y0 = (v[h].x - mean) * rstd * gv.x + ev.x;
+        const float y1 = (v[h].y - mean) * rstd * gv.y + ev.y;
+        const float y2 = (v[h].z - mean) * rstd * gv.z + ev.z;
+        const float y3 = (v[h].w - mean) * rstd * gv.w + ev.w;
+        *reinterpret_cast<float4*>(a.X + (size_t)m * H + n) = make_float4(y0, y1, y2, y3);
+        if constexpr (P::kIsBF16) store4<P>(a.Xb + ((size_t)m * H + n) * 2, y0, y1, y2, y3);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1150,7 +1215,7 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
 
 template <class P, int NT, int NBH>
 hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
-    const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
+    const dim3 blocks((a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
     auto kern = ffn_kernel<P, NT, NBH>;
     const size_t lds = 131072 + (size_t)a.F * 4;
     static size_t configured = 0;            // once per process and size: not a stream operation
@@ -1159,7 +1224,10 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, blocks, dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.partial) return e;
+    hipLaunchKernelGGL(ffn_reduce_ln_kernel<P>, dim3((a.M + 3) / 4), dim3(256), 0, s, a, a.splits);
     return hipGetLastError();
 }
 

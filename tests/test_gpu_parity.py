@@ -430,3 +430,15 @@ def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
     oracle = O.from_features(state, feats.cpu(), frames).numpy()
     assert np.abs(ppg - oracle).max() < FP32_TOL
     w2v2fb._models.clear()
+
+
+def test_graphed_encode_helper():
+    engine, state = eng(precision='bf16')
+    gen = torch.Generator().manual_seed(4)
+    run = engine.graphed(4, 100)
+    for _ in range(2):
+        feats = torch.randn(4, 80, 100, generator=gen).half()
+        out = run(feats.cuda()).clone()
+        torch.cuda.synchronize()
+        ref = engine.encode(feats.cuda(), [100] * 4)
+        assert (out - ref).abs().max() == 0
