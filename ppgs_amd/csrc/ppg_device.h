@@ -94,6 +94,36 @@ __device__ __forceinline__ void store4(void* dst, float a, float b, float c, flo
     }
 }
 
+// Paired feature blocks.  In the accumulator layout a lane owns 4 consecutive
+// tile rows (4g + r) of every 16-row block, i.e. 8-byte bf16 stores scattered
+// over 16 token rows -- the slowest pattern the store path has (tools/
+// store_probe.hip: 3.5 TB/s against 5.4 TB/s for 16-byte pieces).  The engine
+// therefore uploads weight rows so that tile row 16e + 4g + r of every 32-row
+// group computes natural feature 8g + 4e + r (pair_row): the lane's values of
+// blocks 2p and 2p+1 are then the 8 consecutive features 32p + 8g .. + 7, one
+// 16-byte store.  Nothing else changes: outputs stay in natural feature order.
+__host__ __device__ inline int pair_row(int j) {          // natural feature computed by tile row j
+    const int s = j & 31;
+    return (j & ~31) + 8 * ((s & 15) >> 2) + 4 * (s >> 4) + (s & 3);
+}
+__device__ __forceinline__ int pair_feature(int nb, int g) {   // first of the lane's 4 features of block nb
+    return (nb >> 1) * 32 + 8 * g + 4 * (nb & 1);
+}
+// put() the lane's 4 values of block 2p (e = 0), then of block 2p+1 (e = 1);
+// dst8 = address of feature 32p + 8g.  bf16: one 16-byte store at e = 1.
+template <class P>
+struct PairStore {
+    uint32_t lo0, lo1;
+    __device__ __forceinline__ void put(void* dst8, int e, float a, float b, float c, float d) {
+        if constexpr (P::kIsBF16) {
+            if (e == 0) { lo0 = pack_bf16x2(a, b); lo1 = pack_bf16x2(c, d); }
+            else *reinterpret_cast<u32x4*>(dst8) = u32x4{lo0, lo1, pack_bf16x2(a, b), pack_bf16x2(c, d)};
+        } else {
+            reinterpret_cast<float4*>(dst8)[e] = make_float4(a, b, c, d);
+        }
+    }
+};
+
 __device__ __forceinline__ float wave_sum_g(float v) {   // sum over the 4 lane groups g
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
@@ -158,7 +188,6 @@ struct FfnArgs {
     int F;
     int M;
     unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
-    int variant;              // 0: one wave per SIMD (ffn_kernel); 1: A/B wave pairs (ffn_ab_kernel)
     float* partial;           // split-hidden mode: [splits][M][H] fp32 partial sums, else null
     int splits;
 };

@@ -202,7 +202,6 @@ struct PpgEngine {
     int num_cus = 256;
     bool ffn_fused = true;
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
-    int ffn_variant = 0;
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
                             // but kernels of the two halves then overlap and per-kernel timings blur)
     std::vector<hipStream_t> side_streams;
@@ -308,7 +307,7 @@ void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) 
     int nt = choose_nt(e, M, max_nt);
     int splits = 1;
     const int chunks = e->cfg.ffn_channels / (32768 / (e->cfg.hidden_channels * e->sz));
-    if (e->ffn_split && e->ffn_fused && e->ffn_variant == 0 && e->ffn_nt == 0) {
+    if (e->ffn_split && e->ffn_fused && e->ffn_nt == 0) {
         const int tiles_max_nt = (M + 64 * max_nt - 1) / (64 * max_nt);
         // only when the tiles would leave 7/8 of the chip idle: the partial-sum
         // round trip costs about as much as it saves above that (measured: 64 x 160
@@ -580,7 +579,6 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
-    if (const char* s = getenv("PPGS_AMD_FFN_AB")) e->ffn_variant = atoi(s);
     if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < e->num_streams; ++i) {
@@ -609,7 +607,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         const float* w = wts->input_weight;
         const int Cp = e->Cp;
         rc = upload_matrix(E, H, 5 * Cp, H, e->in_total_groups * e->KG,
-                           [&](int h, int k) { const int tap = k / Cp, c = k % Cp; return c < C ? w[((size_t)h * C + c) * 5 + tap] : 0.f; },
+                           [&](int row, int k) { const int h = pair_row(row), tap = k / Cp, c = k % Cp; return c < C ? w[((size_t)h * C + c) * 5 + tap] : 0.f; },
                            &e->w_in);
         if (rc) return rc;
         if ((rc = upload_f32(E, wts->input_bias, H, 0, &e->b_in))) return rc;
@@ -628,10 +626,14 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         auto plain = [&](const float* w, int rows, int cols, char** dst) {
             return upload_matrix(E, rows, cols, rows, cols, [&](int r, int c) { return w[(size_t)r * cols + c]; }, dst);
         };
-        if ((rc = plain(wts->in_proj_weight[l], 3 * H, H, &d.wqkv))) return rc;
-        if ((rc = plain(wts->out_proj_weight[l], H, H, &d.wo))) return rc;
+        // output features in paired-block order (pair_row, ppg_device.h): tile row r computes feature pair_row(r)
+        auto paired = [&](const float* w, int rows, int cols, char** dst) {
+            return upload_matrix(E, rows, cols, rows, cols, [&](int r, int c) { return w[(size_t)pair_row(r) * cols + c]; }, dst);
+        };
+        if ((rc = paired(wts->in_proj_weight[l], 3 * H, H, &d.wqkv))) return rc;
+        if ((rc = paired(wts->out_proj_weight[l], H, H, &d.wo))) return rc;
         if ((rc = plain(wts->linear1_weight[l], F, H, &d.w1))) return rc;
-        if ((rc = plain(wts->linear2_weight[l], H, F, &d.w2))) return rc;
+        if ((rc = paired(wts->linear2_weight[l], H, F, &d.w2))) return rc;
         {   // pack_w2: k-slot order of the fused FFN's phase-B fragments.
             // bf16: inside each 32-wide hidden group, slot 8g + 4e + r holds
             // hidden 16e + 4g + r (the two phase-A accumulators e of lane
@@ -639,7 +641,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
             const float* w = wts->linear2_weight[l];
             const bool bf = e->sz == 2;
             rc = upload_matrix(E, H, F, H, F,
-                               [&](int r, int c) {
+                               [&](int row, int c) {
+                                   const int r = pair_row(row);
                                    if (!bf) return w[(size_t)r * F + c];
                                    const int grp = c / 32, s = c % 32, g = s / 8, ee = (s % 8) / 4, rr = s % 4;
                                    return w[(size_t)r * F + grp * 32 + 16 * ee + 4 * g + rr];
@@ -807,7 +810,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             if (e->ffn_fused) {
                 FfnArgs a{};
                 a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
-                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr; a.variant = e->ffn_variant;
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
                 a.splits = ws.ffn_splits;
                 a.partial = ws.ffn_splits > 1 ? reinterpret_cast<float*>(base + ws.part) : nullptr;
                 LAUNCH_OK(ppg::launch_ffn(prec, a, ws.ffn_nt, s), "ffn");

@@ -204,7 +204,7 @@ __device__ __forceinline__ void lds_stream(const uint32_t (&fb)[L::VAR], USE use
 
 // ---------------------------------------------------------------------------
 // LayerNorm(acc + bias + residual) epilogue, acc in the transposed C layout
-// (lane: token = tok0 + 16t + idx, features nb*16 + 4g + r).
+// (lane: token = tok0 + 16t + idx, features pair_feature(nb, g) + r).
 // ---------------------------------------------------------------------------
 template <class P, int NB, int NT>
 __device__ __forceinline__ void resln_epilogue(
@@ -220,7 +220,7 @@ __device__ __forceinline__ void resln_epilogue(
         float sum = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const int n = nb * 16 + 4 * g;
+            const int n = pair_feature(nb, g);
             const float4 bv = *reinterpret_cast<const float4*>(bias + n);
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) rv = *reinterpret_cast<const float4*>(xrow + n);
@@ -242,9 +242,10 @@ __device__ __forceinline__ void resln_epilogue(
         }
         const float var = wave_sum_g(sq) / (float)H;
         const float rstd = 1.0f / sqrtf(var + kLnEps);
+        PairStore<P> pair;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const int n = nb * 16 + 4 * g;
+            const int n = pair_feature(nb, g);
             const float4 gv = *reinterpret_cast<const float4*>(gamma + n);
             const float4 ev = *reinterpret_cast<const float4*>(beta + n);
             const float y0 = (acc[nb][t][0] - mean) * rstd * gv.x + ev.x;
@@ -253,8 +254,7 @@ __device__ __forceinline__ void resln_epilogue(
             const float y3 = (acc[nb][t][3] - mean) * rstd * gv.w + ev.w;
             if (ok) {
                 *reinterpret_cast<float4*>(xrow + n) = make_float4(y0, y1, y2, y3);
-                if constexpr (P::kIsBF16)
-                    store4<P>(Xb + ((size_t)m * H + n) * 2, y0, y1, y2, y3);
+                if constexpr (P::kIsBF16) pair.put(Xb + ((size_t)m * H + (n & ~7)) * 2, nb & 1, y0, y1, y2, y3);
             }
         }
     }
@@ -437,9 +437,10 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             if (m >= a.M) continue;
             const bool live = tm[t].w >= 0 && tm[t].tt < tm[t].frames;
             const bool valid = live && tm[t].tt < tm[t].valid;
+            PairStore<P> pair;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int n = n0 + nb * 16 + 4 * g;
+                const int n = n0 + pair_feature(nb, g);
                 float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live) {
                     y = *reinterpret_cast<const float4*>(a.pe + (size_t)tm[t].tt * a.H + n);
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                     }
                 }
                 *reinterpret_cast<float4*>(a.X + (size_t)m * a.H + n) = y;
-                if constexpr (P::kIsBF16) store4<P>(a.Xb + ((size_t)m * a.H + n) * 2, y.x, y.y, y.z, y.w);
+                if constexpr (P::kIsBF16) pair.put(a.Xb + ((size_t)m * a.H + (n & ~7)) * 2, nb & 1, y.x, y.y, y.z, y.w);
             }
         }
     } else if constexpr (EPI == EPI_QKV) {
@@ -461,38 +462,58 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             for (int t = 0; t < NT; ++t) {
                 const int m = tok0 + 16 * t + idx;
                 if (m >= a.M) continue;
+                PairStore<P> pair;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int n = n0 + nb * 16 + 4 * g;
+                    const int n = n0 + pair_feature(nb, g);
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                    store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes,
-                              acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
-                              acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
+                    pair.put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
+                             acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
+                             acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
                 }
             }
         } else {
-            // swapped operands: lane holds tokens 4g..4g+3 of block t for
-            // feature nb*16 + idx.  bf16: columns are permuted inside 32-token
-            // groups (position 8g + 4e + r, e = parity of the 16-token block)
-            // so that the PV A-fragment of attn_kernel is one 16-byte read.
+            // swapped operands: lane holds tokens 4g..4g+3 of block t for tile
+            // row nb*16 + idx; V^T rows stay in tile order (attn_kernel's
+            // output accumulator then owns 8 consecutive head features, see
+            // pair_row).  bf16: columns are permuted inside 32-token groups
+            // (position 8g + 4e + r, e = parity of the 16-token block) so that
+            // the PV A-fragment of attn_kernel is one 16-byte read -- and an
+            // (even, odd) block pair of this wave is one 16-byte store.
+            int vw[NT], vcol[NT];        // wave-uniform: window and first column (g = 0) of block t
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int mb = tok0 + 16 * t;            // wave-uniform block start
-                if (mb >= a.M) continue;
-                const int w = a.blk_win[mb >> 4];
-                if (w < 0) continue;
-                const int ttb = mb - a.win[w].tok_off;   // multiple of 16
-                int col;
-                if constexpr (P::kIsBF16) col = a.win[w].vt_off + (ttb >> 5) * 32 + 8 * g + 4 * ((ttb >> 4) & 1);
-                else col = a.win[w].vt_off + ttb + 4 * g;
+                const int mb = tok0 + 16 * t;
+                vw[t] = mb < a.M ? a.blk_win[mb >> 4] : -1;
+                vcol[t] = -1;
+                if (vw[t] >= 0) {
+                    const int ttb = mb - a.win[vw[t]].tok_off;   // multiple of 16
+                    if constexpr (P::kIsBF16) vcol[t] = a.win[vw[t]].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
+                    else vcol[t] = a.win[vw[t]].vt_off + ttb;
+                }
+            }
+            bool done_with_previous = false;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (done_with_previous) { done_with_previous = false; continue; }
+                if (vw[t] < 0) continue;
+                constexpr int kLast = NT - 1;
+                const int tn = t < kLast ? t + 1 : t;
+                const bool paired = P::kIsBF16 && t < kLast && vw[tn] == vw[t] && (vcol[t] & 4) == 0;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int n = n0 + nb * 16 + idx;
-                    const float bv = a.bias[n];
-                    store4<P>(a.vt + ((size_t)(n - a.v_start) * a.vt_ld + col) * P::kBytes,
-                              acc[nb][t][0] + bv, acc[nb][t][1] + bv,
-                              acc[nb][t][2] + bv, acc[nb][t][3] + bv);
+                    const int row = n0 + nb * 16 + idx;                       // tile row
+                    const float bv = a.bias[n0 + pair_row(nb * 16 + idx)];
+                    char* dst = a.vt + ((size_t)(row - a.v_start) * a.vt_ld + vcol[t] + (P::kIsBF16 ? 8 : 4) * g) * P::kBytes;
+                    if (paired) {
+                        *reinterpret_cast<u32x4*>(dst) = u32x4{
+                            pack_bf16x2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), pack_bf16x2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
+                            pack_bf16x2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv), pack_bf16x2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv)};
+                    } else {
+                        store4<P>(dst, acc[nb][t][0] + bv, acc[nb][t][1] + bv, acc[nb][t][2] + bv, acc[nb][t][3] + bv);
+                    }
                 }
+                done_with_previous = paired;
             }
         }
     } else if constexpr (EPI == EPI_RELU) {
@@ -753,7 +774,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (m >= a.M) continue;
 #pragma unroll
             for (int nb = 0; nb < NBH; ++nb)
-                *reinterpret_cast<float4*>(part + (size_t)m * H + nb * 16 + 4 * g) =
+                *reinterpret_cast<float4*>(part + (size_t)m * H + pair_feature(nb, g)) =
                     make_float4(yacc[nb][t][0], yacc[nb][t][1], yacc[nb][t][2], yacc[nb][t][3]);
         }
         return;
@@ -805,199 +826,6 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
         const float y3 = (v[h].w - mean) * rstd * gv.w + ev.w;
         *reinterpret_cast<float4*>(a.X + (size_t)m * H + n) = make_float4(y0, y1, y2, y3);
         if constexpr (P::kIsBF16) store4<P>(a.Xb + ((size_t)m * H + n) * 2, y0, y1, y2, y3);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Fused FFN, wave-specialised variant ("A/B waves"), two waves per SIMD.
-//
-// Workgroup = 8 waves = 4 pairs; pair p owns 16*NT tokens.  Wave p (an
-// "A wave") computes phase A, h^T = relu(W1c x^T + b1), for its pair's tokens
-// and hands the packed bf16 B-fragments to wave p+4 (the "B wave", same SIMD:
-// a workgroup's waves are dealt to the SIMDs cyclically) through LDS; the B
-// wave accumulates y^T += W2c h^T and does the residual + LayerNorm epilogue.
-// A waves run one hidden chunk ahead of B waves.  Each role needs <= 256
-// registers (x fragments + h accumulators | y accumulators), so both waves of
-// a SIMD are resident and each covers the other's LDS waits, DMA issue
-// (global_load_lds blocks the issuing wave ~60 cycles a piece), ReLU/pack
-// VALU and barrier skew -- what the single-wave ffn_kernel cannot hide.
-//
-// Interval i (i = 0 .. NC):  A waves: A(i)      reads W1 tile i
-//                            B waves: B(i-1)    reads W2 tile i-1, h(i-1) in registers
-//   both issue their share of the DMA for W1(i+1) and W2(i) at interval start
-//   barrier #1 (DMA landed, h(i-1) consumed) -> A waves write h(i) to LDS
-//   barrier #2 -> B waves load h(i) into registers
-// LDS: W1 x2 (64 KiB) | W2 x2 (64 KiB) | h hand-off (4 pairs) | b1.
-// ---------------------------------------------------------------------------
-// PAIRS = 4: 8 waves, 2 per SIMD (<= 256 registers);  PAIRS = 6: 12 waves, 3 per
-// SIMD (<= 168 registers, 32-token pairs): 192 tokens per workgroup like the
-// single-wave kernel's 48-token tiles, i.e. one round of 214 workgroups at C2.
-template <class P, int NT, int NBH, int PAIRS>
-__global__ __launch_bounds__(128 * PAIRS, PAIRS / 2) void ffn_ab_kernel(FfnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int H = NBH * 16;
-    constexpr int ROW1 = H * P::kBytes;
-    constexpr int XG = ROW1 / 64;
-    constexpr int HC = 32768 / ROW1;
-    constexpr int HB = HC / 16;
-    constexpr int ROW2 = HC * P::kBytes;
-    constexpr int HG = ROW2 / 64;
-    constexpr int HBUF_PAIR = HG * NT * 1024;        // one 1 KiB fragment per (kg, t)
-    char* ldsh = smem + 131072;
-    char* ldsb1 = ldsh + PAIRS * HBUF_PAIR;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. 2*PAIRS-1
-    const int role = wave >= PAIRS ? 1 : 0;                        // 0 = A wave, 1 = B wave
-    const int pair = wave - role * PAIRS;
-    const int idx = lane & 15;
-    const int g = lane >> 4;
-    const int tok0 = (blockIdx.x * PAIRS + pair) * 16 * NT;
-    const int NC = a.F / HC;
-    const uint32_t lds0 = lds_addr(smem);
-    char* hpair = ldsh + pair * HBUF_PAIR;
-
-    const int rot = (blockIdx.x >> 3) % NC;
-    auto hidden_chunk = [&](int c) { const int r = c + rot; return r >= NC ? r - NC : r; };
-    // the first 8 waves share the DMA of a tile (4 pieces each)
-    auto stage_w1 = [&](int c) {
-        if (wave < 8) stage_tile<HC, ROW1, 8>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
-    };
-    auto stage_w2 = [&](int c) {
-        if (wave < 8) stage_tile<H, ROW2, 8>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
-    };
-    auto interval_dma = [&](int i) {
-        if (i + 1 < NC) stage_w1(i + 1);
-        if (i < NC) stage_w2(i);
-    };
-
-    stage_w1(0);
-    for (int i = tid; i < a.F / 4; i += 128 * PAIRS)
-        reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
-
-    using LA = FragLayout<ROW1, HB>;
-    using LB = FragLayout<ROW2, NBH>;
-
-    if (role == 0) {
-        // ------------------------------ A waves -----------------------------
-        const char* actp = P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X);
-        u32x4 xf[XG][NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int m = tok0 + 16 * t + idx;
-#pragma unroll
-            for (int kg = 0; kg < XG; ++kg) {
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (m < a.M) v = *reinterpret_cast<const u32x4*>(actp + (size_t)m * ROW1 + kg * 64 + g * 16);
-                xf[kg][t] = v;
-            }
-        }
-        dma_wait_barrier();
-        for (int i = 0; i <= NC; ++i) {
-            u32x4 hf[HG][NT];
-            if (i < NC) {
-                u32x4 b1f[HB];
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
-                    ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (hidden_chunk(i) * HC + hb * 16 + 4 * g) * 4);
-                interval_dma(i);
-                f32x4 hacc[HB][NT];
-                uint32_t fba[LA::VAR];
-                LA::bases(lds0 + (i & 1) * 32768, idx, g, fba);
-                lds_stream<LA, XG * HB, (PAIRS > 4 ? 4 : 6)>(fba, [&](auto ic, const u32x4& wf) {
-                    constexpr int s_ = decltype(ic)::value;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        if constexpr (s_ / HB == 0) P::mma0(hacc[s_ % HB][t], wf, xf[0][t]);
-                        else P::mma(hacc[s_ % HB][t], wf, xf[s_ / HB][t]);
-                    }
-                });
-                // the stream's last wait was lgkmcnt(0): the older b1 reads landed
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    const u32x4 bv = b1f[hb];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float h0 = fmaxf(hacc[hb][t][0] + __uint_as_float(bv.x), 0.f);
-                        const float h1 = fmaxf(hacc[hb][t][1] + __uint_as_float(bv.y), 0.f);
-                        const float h2 = fmaxf(hacc[hb][t][2] + __uint_as_float(bv.z), 0.f);
-                        const float h3 = fmaxf(hacc[hb][t][3] + __uint_as_float(bv.w), 0.f);
-                        if constexpr (P::kIsBF16) {
-                            if (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
-                            else        { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
-                        } else {
-                            hf[hb][t] = u32x4{__float_as_uint(h0), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
-                        }
-                    }
-                }
-            } else {
-                interval_dma(i);
-            }
-            dma_wait_barrier();                         // barrier #1
-            if (i < NC) {
-#pragma unroll
-                for (int kg = 0; kg < HG; ++kg)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        *reinterpret_cast<u32x4*>(hpair + ((kg * NT + t) * 64 + lane) * 16) = hf[kg][t];
-            }
-            __syncthreads();                            // barrier #2
-        }
-    } else {
-        // ------------------------------ B waves -----------------------------
-        f32x4 yacc[NBH][NT];
-#pragma unroll
-        for (int nb = 0; nb < NBH; ++nb)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dma_wait_barrier();
-        for (int i = 0; i <= NC; ++i) {
-            if (i >= 1) {
-                // h(i-1): written by the A wave before barrier #2 of the previous
-                // interval.  Its first K-group is loaded before this interval's
-                // DMA is issued (an ordinary LDS load behind an in-flight LDS DMA
-                // makes hipcc drain the DMA); later groups by asm reads.
-                constexpr int DB = (NT >= 3 || PAIRS > 4) ? 4 : 6;
-                u32x4 hf[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    hf[t] = *reinterpret_cast<const u32x4*>(hpair + (t * 64 + lane) * 16);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(hf[t]));
-                interval_dma(i);
-#pragma unroll
-                for (int kg = 0; kg < HG; ++kg) {
-                    // fragments of W2 tile rows for K-group kg: a FragLayout over
-                    // the [rows][ROW2] tile restricted to one group (i -> nb)
-                    uint32_t fbb[LB::VAR];
-                    LB::bases(lds0 + 65536 + ((i - 1) & 1) * 32768, idx, g, fbb);
-                    u32x4 hnext[NT];
-                    if (kg + 1 < HG) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            ds_read_b128_asm<0>(hnext[t], lds_addr(hpair) + (((kg + 1) * NT + t) * 64 + lane) * 16);
-                    }
-                    lds_stream_group<LB, NBH, DB>(fbb, kg, [&](auto ic, const u32x4& wf) {
-                        constexpr int s_ = decltype(ic)::value;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) P::mma(yacc[s_][t], wf, hf[t]);
-                    });
-                    if (kg + 1 < HG) {
-                        // the stream's last wait was lgkmcnt(0): hnext landed
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) { asm volatile("" : "+v"(hnext[t])); hf[t] = hnext[t]; }
-                    }
-                }
-            } else {
-                interval_dma(i);
-            }
-            dma_wait_barrier();                         // barrier #1
-            __syncthreads();                            // barrier #2
-        }
-        resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
     }
 }
 
@@ -1164,12 +992,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         const int m = w.tok_off + qw0 + 16 * t + idx;
         const float l = wave_sum_g(lrun[t]);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
+        // V^T rows are in tile order: block db holds head features pair_feature(db, g) + r
+        PairStore<P> pair;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            const int n = head * DH + db * 16 + 4 * g;
-            store4<P>(a.ao + ((size_t)m * a.H + n) * P::kBytes,
-                      oacc[db][t][0] * inv, oacc[db][t][1] * inv,
-                      oacc[db][t][2] * inv, oacc[db][t][3] * inv);
+            const int n = head * DH + pair_feature(db, g);
+            pair.put(a.ao + ((size_t)m * a.H + (n & ~7)) * P::kBytes, db & 1,
+                     oacc[db][t][0] * inv, oacc[db][t][1] * inv,
+                     oacc[db][t][2] * inv, oacc[db][t][3] * inv);
         }
     }
 }
@@ -1231,31 +1061,8 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <class P, int NT, int NBH, int PAIRS>
-hipError_t launch_ffn_ab_t(const FfnArgs& a, hipStream_t s) {
-    const int blocks = (a.M + 16 * NT * PAIRS - 1) / (16 * NT * PAIRS);
-    auto kern = ffn_ab_kernel<P, NT, NBH, PAIRS>;
-    constexpr int HG = (32768 / (NBH * 16 * P::kBytes)) * P::kBytes / 64;      // K-groups of phase B per chunk
-    const size_t lds = 131072 + (size_t)PAIRS * HG * NT * 1024 + (size_t)a.F * 4;
-    if (lds > 163840) return hipErrorInvalidValue;
-    static size_t configured = 0;
-    if (configured < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(128 * PAIRS), lds, s, a);
-    return hipGetLastError();
-}
-
 template <class P>
 hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
-    if (a.variant == 1 && a.H == 256) {
-        if (nt == 1) return launch_ffn_ab_t<P, 1, 16, 4>(a, s);
-        if (nt == 3) return launch_ffn_ab_t<P, 3, 16, 4>(a, s);
-        return launch_ffn_ab_t<P, 2, 16, 4>(a, s);
-    }
-    if (a.variant == 2 && a.H == 256) return launch_ffn_ab_t<P, 2, 16, 6>(a, s);
     if (a.H == 256) {
         if (nt == 1) return launch_ffn_t<P, 1, 16>(a, s);
         if (nt == 3) return launch_ffn_t<P, 3, 16>(a, s);
