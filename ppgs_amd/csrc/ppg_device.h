@@ -173,9 +173,16 @@ struct LinearArgs {
     const int* blk_win;       // window of each 16-token block (-1 = padding)
     const PpgWindow* win;
     int M;                    // rows in the token-major buffers (multiple of 16)
+    unsigned long long* dbg;  // PPG_LIN_TIMING builds: 16 s_memtime stamps per workgroup (tools/lin_timing.py)
 };
 
 struct FfnArgs {
+    // fused attention out-projection + residual + LayerNorm (ffn_kernel<.., OP = true>); Wo == null: not fused
+    const char* ao;           // attention output, token-major [M][H] elements
+    const char* Wo;           // [H][H], rows in paired order
+    const float* bo;
+    const float* g1;          // norm1
+    const float* e1;
     float* X;                 // residual stream, in/out
     char* Xb;                 // act operand / bf16 copy (bf16 mode); null in fp32 mode
     const char* W1;           // [F][H]

@@ -169,6 +169,7 @@ struct DevLayer {
     char* wo; float* bo;
     char* w1; float* b1;
     char* w2; char* w2p; float* b2;
+    char* w1k;            // W1 for the out-proj-fused FFN: fp32 columns in paired order (= w1 in bf16 mode)
     float *g1, *e1, *g2, *e2;
 };
 
@@ -201,6 +202,7 @@ struct PpgEngine {
     int lin_nt = 0;       // same for the linear/conv kernels
     int num_cus = 256;
     bool ffn_fused = true;
+    bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
                             // but kernels of the two halves then overlap and per-kernel timings blur)
@@ -208,6 +210,8 @@ struct PpgEngine {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     unsigned long long* ffn_dbg = nullptr;
+    unsigned long long* lin_dbg = nullptr;   // PPGS_AMD_LIN_TIMING=<kernel class> (PPG_LIN_TIMING builds): stamps of layer 0
+    int lin_dbg_class = -1;
     std::vector<void*> allocs;
     float* pe = nullptr;
     char* w_in = nullptr; float* b_in = nullptr;
@@ -224,9 +228,15 @@ struct PpgEngine {
     ~PpgEngine() {
         (void)hipSetDevice(device);
         if (ffn_dbg) {
-            unsigned long long h[128];
+            unsigned long long h[256];
             (void)hipDeviceSynchronize();
             if (hipMemcpy(h, ffn_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long* t = h + 128 + w * 16;
+                    fprintf(stderr, "ffn prologue wave %d:", w);
+                    for (int k = 1; k < 15; ++k) if (t[k]) fprintf(stderr, " [%d] %llu", k, t[k] - t[0]);
+                    fprintf(stderr, "\n");
+                }
                 for (int w = 0; w < 4; ++w)
                     for (int c = 0; c < 4; ++c) {
                         const unsigned long long* t = h + (w * 4 + c) * 8;
@@ -235,6 +245,16 @@ struct PpgEngine {
                     }
             }
             (void)hipFree(ffn_dbg);
+        }
+        if (lin_dbg) {
+            const size_t n = 16 * 8192;
+            std::vector<unsigned long long> h(n);
+            (void)hipDeviceSynchronize();
+            const char* path = getenv("PPGS_AMD_LIN_TIMING_OUT");
+            FILE* f = fopen(path ? path : "/tmp/lin_timing.bin", "wb");
+            if (f && hipMemcpy(h.data(), lin_dbg, n * 8, hipMemcpyDeviceToHost) == hipSuccess) fwrite(h.data(), 8, n, f);
+            if (f) fclose(f);
+            (void)hipFree(lin_dbg);
         }
         for (auto& kv : plans) if (kv.second->buf) (void)hipFree(kv.second->buf);
         for (hipStream_t st : side_streams) (void)hipStreamDestroy(st);
@@ -589,9 +609,15 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         e->side_streams.push_back(st);
         e->ev_join.push_back(ev);
     }
+    if (const char* v = getenv("PPGS_AMD_OP_FUSED")) e->op_fused = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
+        e->lin_dbg_class = atoi(v);
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->lin_dbg), 16 * 8192 * 8));
+        HIP_OK(hipMemset(e->lin_dbg, 0, 16 * 8192 * 8));
+    }
     if (getenv("PPGS_AMD_FFN_TIMING")) {
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 1024));
-        HIP_OK(hipMemset(e->ffn_dbg, 0, 1024));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 2048));
+        HIP_OK(hipMemset(e->ffn_dbg, 0, 2048));
     }
     if (e->ffn_nt < 0 || e->ffn_nt > 3) e->ffn_nt = 0;
     {
@@ -634,6 +660,12 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         if ((rc = paired(wts->out_proj_weight[l], H, H, &d.wo))) return rc;
         if ((rc = plain(wts->linear1_weight[l], F, H, &d.w1))) return rc;
         if ((rc = paired(wts->linear2_weight[l], H, F, &d.w2))) return rc;
+        d.w1k = d.w1;
+        if (e->sz == 4) {   // the fused prologue hands LN1's fp32 accumulators to phase A in paired K order
+            const float* w = wts->linear1_weight[l];
+            rc = upload_matrix(E, F, H, F, H, [&](int r, int c) { return w[(size_t)r * H + pair_row(c)]; }, &d.w1k);
+            if (rc) return rc;
+        }
         {   // pack_w2: k-slot order of the fused FFN's phase-B fragments.
             // bf16: inside each 32-wide hidden group, slot 8g + 4e + r holds
             // hidden 16e + 4g + r (the two phase-A accumulators e of lane
@@ -786,6 +818,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
             a.W = d.wqkv; a.bias = d.bqkv; a.N = 3 * H;
             a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
+            if (l == 0 && e->lin_dbg_class == PPG_K_QKV) a.dbg = e->lin_dbg;
             LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, lnt, a, 3 * H / 256, s), "qkv");
         }
         {
@@ -797,12 +830,14 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.items = grp.d_items; a.win = grp.d_win; a.M = M;
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
-        {
+        const bool fuse_op = e->ffn_fused && e->op_fused && ws.ffn_splits == 1;
+        if (!fuse_op) {
             Timed t(e, PPG_K_OUTPROJ_LN, s);
             LinearArgs a = base_args();
             a.act = ao; a.lda_bytes = H * e->sz;
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
             a.W = d.wo; a.bias = d.bo; a.N = H; a.gamma = d.g1; a.beta = d.e1;
+            if (l == 0 && e->lin_dbg_class == PPG_K_OUTPROJ_LN) a.dbg = e->lin_dbg;
             LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, lnt_ln, a, 1, s), "out-proj+LN");
         }
         {
@@ -813,6 +848,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
                 a.splits = ws.ffn_splits;
                 a.partial = ws.ffn_splits > 1 ? reinterpret_cast<float*>(base + ws.part) : nullptr;
+                if (fuse_op) { a.ao = ao; a.Wo = d.wo; a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.W1 = d.w1k; }
                 LAUNCH_OK(ppg::launch_ffn(prec, a, ws.ffn_nt, s), "ffn");
             } else {
                 LinearArgs a = base_args();

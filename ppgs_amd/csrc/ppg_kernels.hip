@@ -203,32 +203,144 @@ __device__ __forceinline__ void lds_stream(const uint32_t (&fb)[L::VAR], USE use
 }
 
 // ---------------------------------------------------------------------------
-// LayerNorm(acc + bias + residual) epilogue, acc in the transposed C layout
+// acc <- LayerNorm(acc + bias + X[m][:]), acc in the transposed C layout
 // (lane: token = tok0 + 16t + idx, features pair_feature(nb, g) + r).
+// MODE LN_EPILOGUE: result to X (fp32) and Xb (bf16 copy, bf16 mode).
+// MODE LN_KEEP: result stays in acc, nothing is stored (the fused FFN's LN1:
+//   x1 is both the next GEMM's operand and, left in the accumulators that the
+//   FFN then adds to, the second residual).
+// MODE LN_NO_RESIDUAL: acc already contains the residual; stores like LN_EPILOGUE.
+// lnp = [bias | gamma | beta], H floats each, in LDS: read from global per
+// (feature block, token block) these were 60 % of the epilogue's memory
+// instructions, all queueing behind the residual loads and the stores in the
+// CU's one address unit.  Loops run feature-block-outer so each parameter
+// vector is fetched once for all NT token blocks.
 // ---------------------------------------------------------------------------
-template <class P, int NB, int NT>
-__device__ __forceinline__ void resln_epilogue(
-    f32x4 (&acc)[NB][NT], const float* __restrict__ bias, float* X, char* Xb, int H,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
+enum { LN_EPILOGUE = 0, LN_KEEP = 1, LN_NO_RESIDUAL = 2 };
+template <class P, int NB, int NT, int MODE>
+__device__ __forceinline__ void resln(
+    f32x4 (&acc)[NB][NT], const float* lnp, float* X, char* Xb, int H,
     int tok0, int M, int idx, int g)
 {
+    bool ok[NT];
+    float* xrow[NT];
+    float sum[NT], mean[NT], rstd[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int m = tok0 + 16 * t + idx;
-        const bool ok = m < M;
-        float* xrow = X + (size_t)(ok ? m : 0) * H;
-        float sum = 0.f;
+        ok[t] = m < M;
+        xrow[t] = X + (size_t)(ok[t] ? m : 0) * H;
+        sum[t] = 0.f;
+    }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int n = pair_feature(nb, g);
-            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = pair_feature(nb, g);
+        const float4 bv = *reinterpret_cast<const float4*>(lnp + n);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) rv = *reinterpret_cast<const float4*>(xrow + n);
+            if constexpr (MODE != LN_NO_RESIDUAL) {
+                if (ok[t]) rv = *reinterpret_cast<const float4*>(xrow[t] + n);
+            }
             acc[nb][t][0] += bv.x + rv.x;
             acc[nb][t][1] += bv.y + rv.y;
             acc[nb][t][2] += bv.z + rv.z;
             acc[nb][t][3] += bv.w + rv.w;
-            sum += (acc[nb][t][0] + acc[nb][t][1]) + (acc[nb][t][2] + acc[nb][t][3]);
+            sum[t] += (acc[nb][t][0] + acc[nb][t][1]) + (acc[nb][t][2] + acc[nb][t][3]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        mean[t] = wave_sum_g(sum[t]) / (float)H;
+        float sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[nb][t][r] - mean[t];
+                sq += d * d;
+            }
+        }
+        const float var = wave_sum_g(sq) / (float)H;
+        rstd[t] = 1.0f / sqrtf(var + kLnEps);
+    }
+    PairStore<P> pair[NT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = pair_feature(nb, g);
+        const float4 gv = *reinterpret_cast<const float4*>(lnp + H + n);
+        const float4 ev = *reinterpret_cast<const float4*>(lnp + 2 * H + n);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float y0 = (acc[nb][t][0] - mean[t]) * rstd[t] * gv.x + ev.x;
+            const float y1 = (acc[nb][t][1] - mean[t]) * rstd[t] * gv.y + ev.y;
+            const float y2 = (acc[nb][t][2] - mean[t]) * rstd[t] * gv.z + ev.z;
+            const float y3 = (acc[nb][t][3] - mean[t]) * rstd[t] * gv.w + ev.w;
+            if constexpr (MODE == LN_KEEP) {
+                acc[nb][t] = f32x4{y0, y1, y2, y3};
+            } else if (ok[t]) {
+                *reinterpret_cast<float4*>(xrow[t] + n) = make_float4(y0, y1, y2, y3);
+                if constexpr (P::kIsBF16)
+                    pair[t].put(Xb + ((size_t)(tok0 + 16 * t + idx) * H + (n & ~7)) * 2, nb & 1, y0, y1, y2, y3);
+            }
+        }
+    }
+}
+
+// Cooperative copy of `count` float vectors of H floats each (global, given
+// as pointers) into consecutive LDS rows; the caller synchronises.
+__device__ __forceinline__ void stage_params(float* lds, int H, int tid, const float* p0, const float* p1, const float* p2) {
+    for (int i = tid; i < 3 * H / 4; i += 256) {
+        const int v = i / (H / 4), j = i - v * (H / 4);
+        const float* src = v == 0 ? p0 : (v == 1 ? p1 : p2);
+        reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(src)[j];
+    }
+}
+
+// The fused FFN's LN1: acc <- LayerNorm(acc + bias + X[m][:]) in registers,
+// nothing stored, plus the result packed as the next GEMM's B fragments xf
+// (paired feature blocks 2p, 2p+1 = K-group p; fp32: block nb = K-group nb in
+// the column order W1 was uploaded in).  The accumulators are MFMA results in
+// AGPRs and must be back there for the chunk loop, whose register budget has
+// no slack: one 16-token block at a time moves to VGPRs for the LayerNorm
+// arithmetic, and the asm pins on the accumulators on either side keep the
+// allocator from blending this code's live ranges with the GEMMs' around it
+// (unpinned, it spills most of the accumulators to scratch while they are
+// being computed and the chunk loop runs 15 % slower; pinning xf as well costs
+// 12 % -- measured, PPG_FFN_TIMING).
+template <class P, int NB, int NT, int XG>
+__device__ __forceinline__ void ln_keep(
+    f32x4 (&acc)[NB][NT], u32x4 (&xf)[XG][NT], const float* lnp, const float* X, int H,
+    int tok0, int M, int idx, int g)
+{
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[nb][t]));
+    // residual rows: block t+1 is loaded while block t is normalised
+    auto load_rows = [&](int t, float4 (&rv)[NB]) {
+        const int m = tok0 + 16 * t + idx;
+        const float* xrow = X + (size_t)(m < M ? m : 0) * H;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            rv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) rv[nb] = *reinterpret_cast<const float4*>(xrow + pair_feature(nb, g));
+        }
+    };
+    float4 rcur[NB], rnext[NB];
+    load_rows(0, rcur);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t + 1 < NT) load_rows(t + 1, rnext);
+        f32x4 v[NB];
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = pair_feature(nb, g);
+            const float4 bv = *reinterpret_cast<const float4*>(lnp + n);
+            const float4 rv = rcur[nb];
+            v[nb] = acc[nb][t] + f32x4{bv.x + rv.x, bv.y + rv.y, bv.z + rv.z, bv.w + rv.w};
+            sum += (v[nb][0] + v[nb][1]) + (v[nb][2] + v[nb][3]);
         }
         const float mean = wave_sum_g(sum) / (float)H;
         float sq = 0.f;
@@ -236,26 +348,38 @@ __device__ __forceinline__ void resln_epilogue(
         for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float d = acc[nb][t][r] - mean;
+                const float d = v[nb][r] - mean;
                 sq += d * d;
             }
         }
-        const float var = wave_sum_g(sq) / (float)H;
-        const float rstd = 1.0f / sqrtf(var + kLnEps);
-        PairStore<P> pair;
+        const float rstd = 1.0f / sqrtf(wave_sum_g(sq) / (float)H + kLnEps);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = pair_feature(nb, g);
-            const float4 gv = *reinterpret_cast<const float4*>(gamma + n);
-            const float4 ev = *reinterpret_cast<const float4*>(beta + n);
-            const float y0 = (acc[nb][t][0] - mean) * rstd * gv.x + ev.x;
-            const float y1 = (acc[nb][t][1] - mean) * rstd * gv.y + ev.y;
-            const float y2 = (acc[nb][t][2] - mean) * rstd * gv.z + ev.z;
-            const float y3 = (acc[nb][t][3] - mean) * rstd * gv.w + ev.w;
-            if (ok) {
-                *reinterpret_cast<float4*>(xrow + n) = make_float4(y0, y1, y2, y3);
-                if constexpr (P::kIsBF16) pair.put(Xb + ((size_t)m * H + (n & ~7)) * 2, nb & 1, y0, y1, y2, y3);
+            const float4 gv = *reinterpret_cast<const float4*>(lnp + H + n);
+            const float4 ev = *reinterpret_cast<const float4*>(lnp + 2 * H + n);
+            v[nb][0] = (v[nb][0] - mean) * rstd * gv.x + ev.x;
+            v[nb][1] = (v[nb][1] - mean) * rstd * gv.y + ev.y;
+            v[nb][2] = (v[nb][2] - mean) * rstd * gv.z + ev.z;
+            v[nb][3] = (v[nb][3] - mean) * rstd * gv.w + ev.w;
+        }
+#pragma unroll
+        for (int kg = 0; kg < XG; ++kg) {
+            if constexpr (P::kIsBF16) {
+                xf[kg][t] = u32x4{pack_bf16x2(v[2 * kg][0], v[2 * kg][1]), pack_bf16x2(v[2 * kg][2], v[2 * kg][3]),
+                                  pack_bf16x2(v[2 * kg + 1][0], v[2 * kg + 1][1]), pack_bf16x2(v[2 * kg + 1][2], v[2 * kg + 1][3])};
+            } else {
+                xf[kg][t] = u32x4{__float_as_uint(v[kg][0]), __float_as_uint(v[kg][1]), __float_as_uint(v[kg][2]), __float_as_uint(v[kg][3])};
             }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb][t] = v[nb];
+            asm volatile("" : "+a"(acc[nb][t]));
+        }
+        if (t + 1 < NT) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) rcur[nb] = rnext[nb];
         }
     }
 }
@@ -343,9 +467,43 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     const int n0 = blockIdx.y * NB * 16;
     const bool swap = (EPI == EPI_QKV) && (n0 >= a.v_start);
 
+#ifdef PPG_LIN_TIMING
+    auto stamp = [&](int k) {
+        if (a.dbg && tid == 0 && k < 15)
+            a.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
+    stamp(0);
+    // Window lookups (two dependent global loads) only where window positions
+    // matter: the k-tap convs.  The plain projections read and write every
+    // row below M -- padding rows hold finite values nobody consumes.
+    constexpr bool CONV = EPI == EPI_INCONV || EPI == EPI_OUTCONV;
     TokMeta tm[NT];
+    if constexpr (CONV) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) tm[t] = tok_meta(a.blk_win, a.win, tok0 + 16 * t + idx, a.M);
+        for (int t = 0; t < NT; ++t) tm[t] = tok_meta(a.blk_win, a.win, tok0 + 16 * t + idx, a.M);
+    }
+    // transposed-V pass: window and first column (lane group 0) of each of the
+    // wave's 16-token blocks, wave-uniform; looked up here so the loads are
+    // long done when the epilogue needs them
+    int vw[NT], vcol[NT];
+    if constexpr (EPI == EPI_QKV) {
+        if (swap) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int mb = tok0 + 16 * t;
+                vw[t] = mb < a.M ? a.blk_win[mb >> 4] : -1;
+                vcol[t] = -1;
+                if (vw[t] >= 0) {
+                    const int ttb = mb - a.win[vw[t]].tok_off;   // multiple of 16
+                    if constexpr (P::kIsBF16) vcol[t] = a.win[vw[t]].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
+                    else vcol[t] = a.win[vw[t]].vt_off + ttb;
+                }
+            }
+        }
+    }
 
     const int pad = a.taps >> 1;
     const char* wbase = a.W + (size_t)n0 * a.total_groups * 64;
@@ -363,11 +521,16 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             const int kgi = gk - tap * a.groups_per_tap;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int st = tm[t].tt + tap - pad;
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (tm[t].w >= 0 && gk < a.real_groups && st >= 0 && st < tm[t].frames) {
-                    const int m = tok0 + 16 * t + idx + tap - pad;
-                    v = *reinterpret_cast<const u32x4*>(a.act + (size_t)m * a.lda_bytes + kgi * 64 + g * 16);
+                if constexpr (CONV) {
+                    const int st = tm[t].tt + tap - pad;
+                    if (tm[t].w >= 0 && gk < a.real_groups && st >= 0 && st < tm[t].frames) {
+                        const int m = tok0 + 16 * t + idx + tap - pad;
+                        v = *reinterpret_cast<const u32x4*>(a.act + (size_t)m * a.lda_bytes + kgi * 64 + g * 16);
+                    }
+                } else {
+                    const int m = tok0 + 16 * t + idx;
+                    if (m < a.M) v = *reinterpret_cast<const u32x4*>(a.act + (size_t)m * a.lda_bytes + gk * 64 + g * 16);
                 }
                 af[kg][t] = v;
             }
@@ -384,7 +547,9 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     u32x4 acur[2][NT], anext[2][NT];
     stage_w(0, smem);
     load_act(0, acur);
+    stamp(1);
     dma_wait_barrier();
+    stamp(2);
 
     // SWAP (V pass of the QKV projection) exchanges the MFMA operands so the
     // accumulator comes out token-major-transposed; compile-time per loop.
@@ -417,7 +582,9 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acur[kg][t] = anext[kg][t];
             }
+            stamp(3 + 2 * s);
             dma_wait_barrier();
+            stamp(4 + 2 * s);
         }
     };
     if constexpr (EPI == EPI_QKV) {
@@ -429,7 +596,11 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 
     // ----------------------------- epilogues --------------------------------
     if constexpr (EPI == EPI_RESLN) {
-        resln_epilogue<P, NB, NT>(acc, a.bias, a.X, a.Xb, a.H, a.gamma, a.beta, tok0, a.M, idx, g);
+        // the weight tiles are done with (the loop ended on a barrier): LDS now holds the LN parameters
+        float* lnp = reinterpret_cast<float*>(smem);
+        stage_params(lnp, a.H, tid, a.bias, a.gamma, a.beta);
+        __syncthreads();
+        resln<P, NB, NT, LN_EPILOGUE>(acc, lnp, a.X, a.Xb, a.H, tok0, a.M, idx, g);
     } else if constexpr (EPI == EPI_INCONV) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -458,18 +629,18 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
         }
     } else if constexpr (EPI == EPI_QKV) {
         if (!swap) {
+            PairStore<P> pair[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int m = tok0 + 16 * t + idx;
-                if (m >= a.M) continue;
-                PairStore<P> pair;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + pair_feature(nb, g);
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);     // once for all token blocks
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int n = n0 + pair_feature(nb, g);
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                    pair.put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
-                             acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
-                             acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
+                for (int t = 0; t < NT; ++t) {
+                    const int m = tok0 + 16 * t + idx;
+                    if (m >= a.M) continue;
+                    pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
+                                acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
+                                acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
                 }
             }
         } else {
@@ -480,18 +651,6 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             // (position 8g + 4e + r, e = parity of the 16-token block) so that
             // the PV A-fragment of attn_kernel is one 16-byte read -- and an
             // (even, odd) block pair of this wave is one 16-byte store.
-            int vw[NT], vcol[NT];        // wave-uniform: window and first column (g = 0) of block t
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int mb = tok0 + 16 * t;
-                vw[t] = mb < a.M ? a.blk_win[mb >> 4] : -1;
-                vcol[t] = -1;
-                if (vw[t] >= 0) {
-                    const int ttb = mb - a.win[vw[t]].tok_off;   // multiple of 16
-                    if constexpr (P::kIsBF16) vcol[t] = a.win[vw[t]].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
-                    else vcol[t] = a.win[vw[t]].vt_off + ttb;
-                }
-            }
             bool done_with_previous = false;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -585,6 +744,11 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             }
         }
     }
+#ifdef PPG_LIN_TIMING
+    stamp(13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(14);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -596,7 +760,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 // into the host-side packing of W2, see pack_w2 in ppg_engine.hip).
 // W1/W2 chunk tiles (32 KiB each) are staged global->regs->LDS.
 // ---------------------------------------------------------------------------
-template <class P, int NT, int NBH>
+template <class P, int NT, int NBH, bool OP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = NBH * 16;
@@ -634,13 +798,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto stage_w2 = [&](int c) {
         stage_tile<H, ROW2, 4>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
     };
-    stage_w1(0);
-    stage_w2(0);
-    if (NC > 1) stage_w1(1);
+    // OP: the W1 double buffer first carries the H/HC tiles of W_o
+    constexpr int OT = H / HC;
+    static_assert(OT % 2 == 0, "W_o tiles must leave the W1 buffers in phase");
+    auto stage_wo = [&](int i) {
+        stage_tile<HC, ROW1, 4>(a.Wo + (size_t)i * 32768, (size_t)ROW1, smem + (i & 1) * 32768, wave, lane);
+    };
+    if constexpr (OP) {
+        stage_wo(0);
+        stage_w2(0);
+        stage_wo(1);
+    } else {
+        stage_w1(0);
+        stage_w2(0);
+        if (NC > 1) stage_w1(1);
+    }
     for (int i = tid; i < a.F / 4; i += 256)
         reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
+    // LayerNorm parameters behind b1: [b2 | gamma2 | beta2] and, with OP, [bo | gamma1 | beta1]
+    float* lnp2 = reinterpret_cast<float*>(ldsb1) + a.F;
+    float* lnp1 = lnp2 + 3 * H;
+    stage_params(lnp2, H, tid, a.b2, a.gamma, a.beta);
+    if constexpr (OP) stage_params(lnp1, H, tid, a.bo, a.g1, a.e1);
 
-    const char* actp = P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X);
+    // B fragments of the wave's tokens: x (bf16 copy / fp32 X), or with OP the
+    // attention output, replaced by LN1's result below
+    const char* actp = OP ? a.ao : (P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X));
     u32x4 xf[XG][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -654,10 +837,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     f32x4 yacc[NBH][NT];
+    if constexpr (!OP) {
 #pragma unroll
-    for (int nb = 0; nb < NBH; ++nb)
+        for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) yacc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     using LA = FragLayout<ROW1, HB>;
     using LB = FragLayout<ROW2, NBH>;
@@ -685,19 +870,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // phase A of chunk c: h^T = W1c x^T (fragment i = (kg, hb)); the VALU of
     // `filler(step)` is issued between the MFMAs so the matrix pipe stays fed
-    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NT], auto filler) {
+    // (destination: rows OFF .. OFF + HB of `dst`, an [..][NT] accumulator array)
+    auto phase_a_into = [&](int c, auto& dst, auto off_tag, auto filler) {
+        constexpr int OFF = decltype(off_tag)::value;
         uint32_t fba[LA::VAR];
         LA::bases(lds0 + (c & 1) * 32768, idx, g, fba);
         lds_stream<LA, RA, DEPTH>(fba, [&](auto ic, const u32x4& wf) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if constexpr (i / HB == 0) P::mma0(hdst[i % HB][t], wf, xf[0][t]);
-                else P::mma(hdst[i % HB][t], wf, xf[i / HB][t]);
+                if constexpr (i / HB == 0) P::mma0(dst[OFF + i % HB][t], wf, xf[0][t]);
+                else P::mma(dst[OFF + i % HB][t], wf, xf[i / HB][t]);
             }
             filler(ic);
         });
     };
+    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NT], auto filler) {
+        phase_a_into(c, hdst, std::integral_constant<int, 0>{}, filler);
+    };
+
+#ifdef PPG_FFN_TIMING
+    auto pstamp = [&](int k) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[128 + wave * 16 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto pstamp = [&](int) {};
+#endif
+    pstamp(0);
+    if constexpr (OP) {
+        // x1 = LN1(X + W_o ao + b_o): the out-projection runs like a phase A
+        // per W_o tile, straight into the (not yet live) y accumulators; the
+        // W_o rows are in paired order, so the accumulators of blocks 2p, 2p+1
+        // are K-group p of the next GEMM's B operand (bf16; fp32: W1's columns
+        // are uploaded in the matching order).  x1 also stays in the y
+        // accumulators: the FFN sums on top of it, so the second residual
+        // costs no memory traffic at all.
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                dma_wait_barrier();
+                pstamp(1 + 2 * I);
+                phase_a_into(I, yacc, std::integral_constant<int, I * HB>{}, [](auto) {});
+                __syncthreads();              // buffer I & 1 is free for the tile after next
+                if constexpr (I + 2 < OT) stage_wo(I + 2);
+                else if (I + 2 - OT < NC) stage_w1(I + 2 - OT);
+                pstamp(2 + 2 * I);
+            }(), ...);
+        }(std::make_integer_sequence<int, OT>{});
+        ln_keep<P, NBH, NT, XG>(yacc, xf, lnp1, a.X, H, tok0, a.M, idx, g);
+        pstamp(12);
+        // yacc keeps x1: phase B accumulates W2 h on top of the residual
+    }
+
     // one chunk: [A(c+1) || pack(c)] -> B(c)
 #ifdef PPG_FFN_TIMING
     auto stamp = [&](int c, int k) {
@@ -754,7 +977,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     f32x4 h0[HB][NT], h1[HB][NT];
+    pstamp(13);
     dma_wait_barrier();
+    pstamp(14);
     phase_a(0, h0, [](auto) {});
     __syncthreads();                      // W1 buffer 0 is re-filled by chunk 0's DMA
     for (int c = 0; c < NC; ++c) {
@@ -779,7 +1004,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         return;
     }
-    resln_epilogue<P, NBH, NT>(yacc, a.b2, a.X, a.Xb, H, a.gamma, a.beta, tok0, a.M, idx, g);
+    // (OP: nothing derived from the lane coordinates before the chunk loop may stay live across it)
+    int tok0e = tok0, idxe = idx, ge = g;
+    if constexpr (OP) asm volatile("" : "+s"(tok0e), "+v"(idxe), "+v"(ge));
+    resln<P, NBH, NT, OP ? LN_NO_RESIDUAL : LN_EPILOGUE>(yacc, lnp2, a.X, a.Xb, H, tok0e, a.M, idxe, ge);
 }
 
 // Second half of the split-hidden FFN: X <- LN(X + b2 + sum_s partial[s]).
@@ -1036,18 +1264,19 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
     case EPI_RELU:   return launch_linear_nt<P, 16, EPI_RELU>(nt, a, ypasses, s);
     case EPI_OUTCONV:return launch_linear_nt<P, 3, EPI_OUTCONV>(nt, a, ypasses, s);
     case EPI_RESLN:
-        if (nb == 16) return launch_linear_nt<P, 16, EPI_RESLN>(nt, a, ypasses, s);
+        // one 16-token block per wave: the LayerNorm epilogue holds a whole feature row per token in registers
+        if (nb == 16) return launch_linear_t<P, 1, 16, EPI_RESLN>(a, ypasses, s);
         if (nb == 32) return launch_linear_t<P, 1, 32, EPI_RESLN>(a, ypasses, s);
         return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
 
-template <class P, int NT, int NBH>
+template <class P, int NT, int NBH, bool OP>
 hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const dim3 blocks((a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
-    auto kern = ffn_kernel<P, NT, NBH>;
-    const size_t lds = 131072 + (size_t)a.F * 4;
+    auto kern = ffn_kernel<P, NT, NBH, OP>;
+    const size_t lds = 131072 + (size_t)a.F * 4 + 6 * (size_t)a.H * 4;
     static size_t configured = 0;            // once per process and size: not a stream operation
     if (configured < lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1061,15 +1290,24 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <class P, bool OP>
+hipError_t launch_ffn_op(const FfnArgs& a, int nt, hipStream_t s) {
+    if (a.H == 256) {
+        if (nt == 1) return launch_ffn_t<P, 1, 16, OP>(a, s);
+        if constexpr (P::kIsBF16) if (nt == 3) return launch_ffn_t<P, 3, 16, OP>(a, s);
+        return launch_ffn_t<P, 2, 16, OP>(a, s);
+    }
+    if (a.H == 512) return launch_ffn_t<P, 1, 32, OP>(a, s);
+    return hipErrorInvalidValue;
+}
+
 template <class P>
 hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
-    if (a.H == 256) {
-        if (nt == 1) return launch_ffn_t<P, 1, 16>(a, s);
-        if (nt == 3) return launch_ffn_t<P, 3, 16>(a, s);
-        return launch_ffn_t<P, 2, 16>(a, s);
+    if (a.Wo != nullptr) {
+        if (a.partial != nullptr) return hipErrorInvalidValue;   // every split would redo the out-projection
+        return launch_ffn_op<P, true>(a, nt, s);
     }
-    if (a.H == 512) return launch_ffn_t<P, 1, 32>(a, s);
-    return hipErrorInvalidValue;
+    return launch_ffn_op<P, false>(a, nt, s);
 }
 
 template <class P>

@@ -19,8 +19,9 @@ KERNEL_CLASSES = (
     'gather', 'inconv', 'qkv', 'attention', 'outproj_ln', 'ffn',
     'outconv_softmax', 'frontend')
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                         'libppgs_amd.so')
+# PPGS_AMD_LIB: an alternative build of the same library (kernel experiments)
+_LIB_PATH = os.environ.get('PPGS_AMD_LIB') or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), 'libppgs_amd.so')
 _lib = None
 _lib_lock = threading.Lock()
 
