@@ -181,7 +181,12 @@ def main():
         # FLOPs of ONE launch: the batch's FFN work of one layer, divided by the
         # launches per layer (>1 when the engine splits the batch over streams)
         launches_per_layer = max(ffn_launches // (5 * args.steps), 1)
-        ffn_flops = 4.0 * hidden * ffn * info.processed_frames / launches_per_layer
+        # (FFN 2*2*H*F per processed frame; the attention
+        # out-projection's 2*H*H ride along when the engine fuses it into the
+        # same kernel -- then no separate out-proj launch shows up)
+        op_fused = kernels['outproj_ln'][1] == 0
+        flops_per_frame = 4.0 * hidden * ffn + (2.0 * hidden * hidden if op_fused else 0.0)
+        ffn_flops = flops_per_frame * info.processed_frames / launches_per_layer
         ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_launches, 1)) / 1e12
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_FP32_TFLOPS
         step_flops = BATCH * data.flops(FRAMES)
@@ -207,7 +212,8 @@ def main():
                 'parallelism': f'utterance-sharded x{world}, no data-path collective',
             },
             'roofline': {
-                'kernel': 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)',
+                'kernel': ('ffn_kernel (fused out-proj+residual+LN1, W1+ReLU+W2+residual+LN2)' if op_fused
+                           else 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)'),
                 'bound': 'mfma',
                 'achieved': ffn_tflops,
                 'peak': peak,

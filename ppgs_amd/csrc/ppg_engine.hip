@@ -513,8 +513,8 @@ int frontend_for(int device, Frontend** out) {
         HIP_OK(hipSetDevice(device));
         std::vector<float> hann(1024);
         for (int n = 0; n < 1024; ++n) hann[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / 1024.0));
-        std::vector<float2> tw(768);
-        for (int j = 0; j < 768; ++j) {
+        std::vector<float2> tw(1024);
+        for (int j = 0; j < 1024; ++j) {
             const double ang = -2.0 * M_PI * j / 1024.0;
             tw[j] = make_float2((float)cos(ang), (float)sin(ang));
         }
@@ -530,6 +530,10 @@ int frontend_for(int device, Frontend** out) {
             count[m] = first < 0 ? 0 : last - first + 1;
             offset[m] = (int)packed.size();
             for (int k = 0; k < count[m]; ++k) packed.push_back(dense[(size_t)m * 513 + start[m] + k]);
+            // rows padded with zero weights to a multiple of 8 bins (the kernel's unroll);
+            // start + count stays within the 520-float magnitude rows
+            while (count[m] % 8) { packed.push_back(0.f); ++count[m]; }
+            if (start[m] + count[m] > 520) return fail(PPG_EINVAL, "mel filter %d overruns the magnitude row", m);
         }
         auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
             void* p = nullptr;
@@ -546,6 +550,18 @@ int frontend_for(int device, Frontend** out) {
         if ((rc = up(count.data(), 320, (const void**)&f.tb.mel_count))) return rc;
         if ((rc = up(offset.data(), 320, (const void**)&f.tb.mel_offset))) return rc;
         if ((rc = up(packed.data(), packed.size() * 4, (const void**)&f.tb.mel_weight))) return rc;
+        if ((int)packed.size() > ppg::kMaxMelWeights) return fail(PPG_EINVAL, "mel filterbank: %zu packed weights", packed.size());
+        f.tb.mel_weights = (int)packed.size();
+        // filters, longest first
+        std::vector<int> order(80);
+        for (int m = 0; m < 80; ++m) order[m] = m;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count[a] > count[b]; });
+        if ((rc = up(order.data(), order.size() * 4, (const void**)&f.tb.mel_task))) return rc;
+        f.tb.dbg = nullptr;
+        if (getenv("PPGS_AMD_FE_TIMING")) {
+            std::vector<unsigned long long> zeros(64, 0);
+            if ((rc = up(zeros.data(), 512, (const void**)&f.tb.dbg))) return rc;
+        }
         f.ready = true;
     }
     *out = &f;
@@ -919,6 +935,18 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
     }
     hipError_t he = ppg::launch_frontend(f->tb, audio, batch, samples, spec, mel, s);
     if (on) (void)hipEventRecord(ev.b, s);
+    if (f->tb.dbg) {
+        static int dumps = 0;
+        unsigned long long h[64];
+        if (dumps++ < 2 && hipStreamSynchronize(s) == hipSuccess &&
+            hipMemcpy(h, f->tb.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int w = 0; w < 4; ++w) {
+                fprintf(stderr, "frontend wave %d (group 2 of workgroup 0):", w);
+                for (int k = 1; k < 10; ++k) fprintf(stderr, " [%d] %lld", k, (long long)(h[w * 16 + k] - h[w * 16]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     if (he != hipSuccess) return fail(PPG_EDEVICE, "frontend: %s", hipGetErrorString(he));
     return PPG_OK;
 }

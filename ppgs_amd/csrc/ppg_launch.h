@@ -16,13 +16,18 @@ hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArg
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
 
+constexpr int kMaxMelWeights = 1536;   // LDS room for the packed filterbank (1001 non-zeros + interior zeros)
+
 struct FrontendTables {
     const float* hann;        // [1024]
-    const float2* twiddle;    // [768] exp(-2 pi i j / 1024)
+    const float2* twiddle;    // [1024] exp(-2 pi i j / 1024)
     const int* mel_start;     // [80] first bin of each filter
     const int* mel_count;     // [80]
     const int* mel_offset;    // [80] offset into mel_weight
     const float* mel_weight;  // packed non-zeros
+    int mel_weights;          // entries of mel_weight (<= kMaxMelWeights)
+    unsigned long long* dbg;  // PPG_FE_TIMING builds: s_memtime stamps of workgroup 0 (PPGS_AMD_FE_TIMING=1)
+    const int* mel_task;      // [80] filters, longest first: lane l of a pair's wave takes entries l and 127 - l
 };
 
 hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int batch, int samples,
