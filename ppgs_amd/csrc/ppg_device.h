@@ -124,15 +124,29 @@ struct PairStore {
     }
 };
 
-__device__ __forceinline__ float wave_sum_g(float v) {   // sum over the 4 lane groups g
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// Reductions over the 4 lane groups g (lanes l, l+16, l+32, l+48) with the
+// gfx950 row-swap VALU instructions instead of LDS-routed shuffles:
+// v_permlane16_swap(x, x) leaves (x0,x0,x2,x2) / (x1,x1,x3,x3) in its two
+// results (xi = row i), v_permlane32_swap(x, x) leaves (x0,x1,x0,x1) /
+// (x2,x3,x2,x3); one combine after each gives every lane the full result.
+__device__ __forceinline__ float wave_sum_g(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// max of three without the NaN-canonicalising copies fmaxf() drags in for
+// values the compiler cannot prove canonical (MFMA results)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 __device__ __forceinline__ float wave_max_g(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = max3(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return max3(__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[1]));
 }
 
 // Epilogue kinds of linear_kernel
@@ -205,6 +219,7 @@ struct AttnItem {
 };
 
 struct AttnArgs {
+    unsigned long long* dbg;  // PPG_ATTN_TIMING builds: s_memtime stamps of workgroup (0, 0)
     const char* qk;           // [M][2H] (q | k), elements
     int qk_ld_bytes;
     const char* vt;           // [H][vt_ld]

@@ -90,6 +90,15 @@ void split_groups(Plan* plan, int ngroups, int qtile) {
             grp.vt_tokens = win.vt_off + round_up(win.frames, 32);
             grp.windows.push_back(win);
         }
+        // Launch order = item order: longest first (keys actually visited; the
+        // causal flag only shortens early query tiles, which keeps this order a
+        // good proxy).  Workgroups are handed to CU slots in order, so a long item
+        // dispatched late would run alone at the end of the kernel (batch 32 x
+        // 1000 frames: 500/500/250-frame windows in utterance order finish at 2.0
+        // long-item times, sorted at 1.5).
+        std::stable_sort(grp.items.begin(), grp.items.end(), [&](const AttnItem& x, const AttnItem& y) {
+            return grp.windows[x.window].valid > grp.windows[y.window].valid;
+        });
         plan->groups.push_back(std::move(grp));
     }
 }
@@ -210,6 +219,7 @@ struct PpgEngine {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     unsigned long long* ffn_dbg = nullptr;
+    unsigned long long* attn_dbg = nullptr;  // PPGS_AMD_ATTN_TIMING (PPG_ATTN_TIMING builds)
     unsigned long long* lin_dbg = nullptr;   // PPGS_AMD_LIN_TIMING=<kernel class> (PPG_LIN_TIMING builds): stamps of layer 0
     int lin_dbg_class = -1;
     std::vector<void*> allocs;
@@ -245,6 +255,18 @@ struct PpgEngine {
                     }
             }
             (void)hipFree(ffn_dbg);
+        }
+        if (attn_dbg) {
+            unsigned long long h[64];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(h, attn_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                for (int w = 0; w < 4; ++w)
+                    for (int c = 0; c < 2; ++c) {
+                        const unsigned long long* t = h + (w * 2 + c) * 8;
+                        fprintf(stderr, "attn timing wave %d tile %d: dma-issue %llu  scores+softmax %llu  PV %llu  vmcnt %llu  barrier %llu | total %llu\n",
+                                w, c + 2, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+                    }
+            (void)hipFree(attn_dbg);
         }
         if (lin_dbg) {
             const size_t n = 16 * 8192;
@@ -631,6 +653,10 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->lin_dbg), 16 * 8192 * 8));
         HIP_OK(hipMemset(e->lin_dbg, 0, 16 * 8192 * 8));
     }
+    if (getenv("PPGS_AMD_ATTN_TIMING")) {
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->attn_dbg), 512));
+        HIP_OK(hipMemset(e->attn_dbg, 0, 512));
+    }
     if (getenv("PPGS_AMD_FFN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 2048));
         HIP_OK(hipMemset(e->ffn_dbg, 0, 2048));
@@ -844,6 +870,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
             a.items = grp.d_items; a.win = grp.d_win; a.M = M;
+            a.dbg = l == 0 ? e->attn_dbg : nullptr;
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
         const bool fuse_op = e->ffn_fused && e->op_fused && ws.ffn_splits == 1;

@@ -1109,9 +1109,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const char* kbase = a.qk + (size_t)w.tok_off * a.qk_ld_bytes + ((size_t)a.H + (size_t)head * DH) * P::kBytes;
     const char* vbase = a.vt + (size_t)head * DH * a.vt_ld_bytes + (size_t)w.vt_off * P::kBytes;
 
-    auto stage = [&](int kt, char* buf) {
-        stage_tile<KT, ROWK, 4>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, buf, wave, lane);
-        stage_tile<DH, ROWV, 4>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, buf + 16384, wave, lane);
+    // LDS: K tiles at 0 / 16 KiB, V^T tiles at 32 / 48 KiB (DMA double buffers).
+    // K runs one tile ahead of V: the scores of tile kt+1 are computed while
+    // the softmax of tile kt runs (see the loop).
+    auto stage_k = [&](int kt) {
+        stage_tile<KT, ROWK, 4>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, smem + (kt & 1) * 16384, wave, lane);
+    };
+    auto stage_v = [&](int kt) {
+        stage_tile<DH, ROWV, 4>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, smem + 32768 + (kt & 1) * 16384, wave, lane);
     };
 
     f32x4 oacc[DB][NTQ];
@@ -1123,87 +1128,132 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) { mrun[t] = -INFINITY; lrun[t] = 0.f; }
 
-    if (ntiles > 0) stage(0, smem);
-    dma_wait_barrier();
-
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const uint32_t ldsk = lds_addr(smem) + (kt & 1) * 32768;
-        const uint32_t ldsv = ldsk + 16384;
-        if (kt + 1 < ntiles) stage(kt + 1, smem + ((kt + 1) & 1) * 32768);
-
-        f32x4 sacc[KB][NTQ];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int t = 0; t < NTQ; ++t) sacc[kb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // fragment i = (kg, kb) = (i / KB, i % KB)
+    const uint32_t lds0 = lds_addr(smem);
+    constexpr int NSTEP = DG * KB;              // fragments of a K tile (16 KiB / 1 KiB)
+    // S^T = K q^T of tile kt into s (fragment i = (kg, kb) = (i / KB, i % KB));
+    // `filler(step)` is VALU work issued between the MFMAs
+    auto scores = [&](int kt, f32x4 (&s)[KB][NTQ], auto filler) {
         using LK = FragLayout<ROWK, KB>;
         uint32_t fbk[LK::VAR];
-        LK::bases(ldsk, idx, g, fbk);
-        lds_stream<LK, DG * KB, 6>(
-            fbk,
-            [&](auto ic, const u32x4& kf) {
-                constexpr int i = decltype(ic)::value;
+        LK::bases(lds0 + (kt & 1) * 16384, idx, g, fbk);
+        lds_stream<LK, NSTEP, 6>(fbk, [&](auto ic, const u32x4& kf) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
-                for (int t = 0; t < NTQ; ++t) P::mma(sacc[i % KB][t], kf, qf[i / KB][t]);
-            });
+            for (int t = 0; t < NTQ; ++t) {
+                if constexpr (i / KB == 0) P::mma0(s[i % KB][t], kf, qf[0][t]);
+                else P::mma(s[i % KB][t], kf, qf[i / KB][t]);
+            }
+            filler(ic);
+        });
+    };
 
-        // Online softmax in the exp2 domain: p = exp2(s*c - m*c), c = log2(e)/sqrt(d),
-        // one FMA + one v_exp_f32 per score; the running max is tracked on the raw
-        // scores (c > 0).  Masking code only runs for tiles that reach past the
-        // valid keys / the causal diagonal; O is rescaled only when a max moved.
-        u32x4 pf[PG][NTQ];
-        const float c = a.scale_log2e;
-        const bool need_mask = (kt + 1) * KT > w.valid || (a.causal && (kt + 1) * KT > qw0);
-#pragma unroll
-        for (int t = 0; t < NTQ; ++t) {
-            const int tq = qw0 + 16 * t + idx;
+    // Online softmax of one tile in the exp2 domain: p = exp2(s*c - m*c),
+    // c = log2(e)/sqrt(d), one FMA + one v_exp_f32 per score; the running max
+    // is tracked on the raw scores (c > 0).  Masking code only runs for tiles
+    // that reach past the valid keys / the causal diagonal; O is rescaled only
+    // when a max moved.  Cut into NPIECE pieces so that it can be issued between
+    // the MFMAs of the next tile's scores: per query block t
+    //   piece 0: mask, row max (lane partial + shuffles over the 4 lane groups)
+    //   piece 1: rescale of the running sum and of O
+    //   piece 2 + kb: exponentials of key block kb, packed as the PV B fragment
+    constexpr int PPT = 2 + KB;
+    constexpr int NPIECE = NTQ * PPT;
+    const float c = a.scale_log2e;
+    float mnew[NTQ], mc[NTQ], psum[NTQ];
+    auto softmax_piece = [&](auto jc, int kt, bool need_mask, f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int t = j / PPT, r = j % PPT;
+        if constexpr (r == 0) {
             if (need_mask) {
+                const int tq = qw0 + 16 * t + idx;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * KT + kb * 16 + 4 * g + r;
-                        if (key >= w.valid || (a.causal && key > tq)) sacc[kb][t][r] = -INFINITY;
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = kt * KT + kb * 16 + 4 * g + e;
+                        if (key >= w.valid || (a.causal && key > tq)) s[kb][t][e] = -INFINITY;
                     }
             }
-            float mx = -INFINITY;
+            float mx = max3(s[0][t][0], s[0][t][1], s[0][t][2]);
+            mx = max3(mx, s[0][t][3], mrun[t]);
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                mx = fmaxf(fmaxf(mx, fmaxf(sacc[kb][t][0], sacc[kb][t][1])), fmaxf(sacc[kb][t][2], sacc[kb][t][3]));
-            mx = wave_max_g(mx);
-            const float mnew = fmaxf(mrun[t], mx);
-            const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;       // fully masked so far: p = exp2(-inf) = 0
-            if (__any(mnew != mrun[t])) {
-                const float alpha = __builtin_amdgcn_exp2f(mrun[t] * c - mc);   // first tile: exp2(-inf) = 0
+            for (int kb = 1; kb < KB; ++kb) {
+                mx = max3(mx, s[kb][t][0], s[kb][t][1]);
+                mx = max3(mx, s[kb][t][2], s[kb][t][3]);
+            }
+            mnew[t] = wave_max_g(mx);           // includes the running max (equal in the 4 lane groups)
+            mc[t] = (mnew[t] == -INFINITY) ? 0.f : mnew[t] * c;       // fully masked so far: p = exp2(-inf) = 0
+        } else if constexpr (r == 1) {
+            if (__any(mnew[t] != mrun[t])) {
+                const float alpha = __builtin_amdgcn_exp2f(mrun[t] * c - mc[t]);   // first tile: exp2(-inf) = 0
                 lrun[t] *= alpha;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
                     oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
                 }
-                mrun[t] = mnew;
+                mrun[t] = mnew[t];
             }
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][0], c, -mc));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][1], c, -mc));
-                const float p2 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][2], c, -mc));
-                const float p3 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][t][3], c, -mc));
-                psum += (p0 + p1) + (p2 + p3);
-                if constexpr (P::kIsBF16) {
-                    if (kb & 1) { pf[kb >> 1][t].z = pack_bf16x2(p0, p1); pf[kb >> 1][t].w = pack_bf16x2(p2, p3); }
-                    else        { pf[kb >> 1][t].x = pack_bf16x2(p0, p1); pf[kb >> 1][t].y = pack_bf16x2(p2, p3); }
-                } else {
-                    pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
-                }
+            psum[t] = 0.f;
+        } else {
+            constexpr int kb = r - 2;
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][0], c, -mc[t]));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][1], c, -mc[t]));
+            const float p2 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][2], c, -mc[t]));
+            const float p3 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][3], c, -mc[t]));
+            psum[t] += (p0 + p1) + (p2 + p3);
+            if constexpr (P::kIsBF16) {
+                if constexpr (kb & 1) { pf[kb >> 1][t].z = pack_bf16x2(p0, p1); pf[kb >> 1][t].w = pack_bf16x2(p2, p3); }
+                else                  { pf[kb >> 1][t].x = pack_bf16x2(p0, p1); pf[kb >> 1][t].y = pack_bf16x2(p2, p3); }
+            } else {
+                pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
             }
-            lrun[t] += psum;
+            if constexpr (kb == KB - 1) lrun[t] += psum[t];
         }
+    };
+
+    if (ntiles > 0) { stage_k(0); stage_v(0); }
+    if (ntiles > 1) stage_k(1);
+    dma_wait_barrier();
+
+    f32x4 scur[KB][NTQ], snext[KB][NTQ];
+    if (ntiles > 0) scores(0, scur, [](auto) {});
+    __syncthreads();                       // K buffer 0 is re-filled by iteration 0's DMA
+
+#ifdef PPG_ATTN_TIMING
+    auto stamp = [&](int kt, int k) {
+        if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && kt >= 2 && kt < 4)
+            a.dbg[(wave * 2 + (kt - 2)) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](int, int) {};
+#endif
+    // iteration kt: DMA K(kt+2), V(kt+1) | scores(kt+1) with softmax(kt) in its MFMA gaps | O += V P(kt)
+    for (int kt = 0; kt < ntiles; ++kt) {
+        stamp(kt, 0);
+        if (kt + 2 < ntiles) stage_k(kt + 2);
+        if (kt + 1 < ntiles) stage_v(kt + 1);
+        stamp(kt, 1);
+        u32x4 pf[PG][NTQ];
+        const bool need_mask = (kt + 1) * KT > w.valid || (a.causal && (kt + 1) * KT > qw0);
+        if (kt + 1 < ntiles) {
+            scores(kt + 1, snext, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                // pieces [(i * NPIECE) / NSTEP, ((i + 1) * NPIECE) / NSTEP) ride on stream step i
+                constexpr int lo = (i * NPIECE) / NSTEP, hi = ((i + 1) * NPIECE) / NSTEP;
+                if constexpr (hi > lo) softmax_piece(std::integral_constant<int, lo>{}, kt, need_mask, scur, pf);
+                if constexpr (hi > lo + 1) softmax_piece(std::integral_constant<int, lo + 1>{}, kt, need_mask, scur, pf);
+                static_assert(hi <= lo + 2, "at most two pieces per step");
+            });
+        } else {
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                (softmax_piece(std::integral_constant<int, J>{}, kt, need_mask, scur, pf), ...);
+            }(std::make_integer_sequence<int, NPIECE>{});
+        }
+        stamp(kt, 2);
         using LV = FragLayout<ROWV, DB>;
         uint32_t fbv[LV::VAR];
-        LV::bases(ldsv, idx, g, fbv);
+        LV::bases(lds0 + 32768 + (kt & 1) * 16384, idx, g, fbv);
         lds_stream<LV, PG * DB, 6>(
             fbv,
             [&](auto ic, const u32x4& vf) {
@@ -1211,7 +1261,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
                 for (int t = 0; t < NTQ; ++t) P::mma(oacc[i % DB][t], vf, pf[i / DB][t]);
             });
-        dma_wait_barrier();
+        stamp(kt, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(kt, 4);
+        __syncthreads();
+        stamp(kt, 5);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) scur[kb][t] = snext[kb][t];
     }
 
 #pragma unroll
