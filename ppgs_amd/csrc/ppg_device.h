@@ -197,6 +197,14 @@ struct FfnArgs {
     const float* bo;
     const float* g1;          // norm1
     const float* e1;
+    // fused Q/K/V projection of the NEXT layer on the kernel's own output (ffn_kernel<.., QKV = true>); Wq == null: not fused
+    const char* Wq;           // [3H][H], rows in paired order (fp32: columns too)
+    const float* bq;
+    char* qk_out;             // [M][2H] (q | k), elements
+    char* vt_out;             // transposed V [H][vt_ld]
+    int vt_ld;
+    const int* blk_win;       // window of each 16-token block (-1 = padding)
+    const PpgWindow* win;
     float* X;                 // residual stream, in/out
     char* Xb;                 // act operand / bf16 copy (bf16 mode); null in fp32 mode
     const char* W1;           // [F][H]

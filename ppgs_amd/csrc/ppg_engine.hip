@@ -178,6 +178,7 @@ struct DevLayer {
     char* wo; float* bo;
     char* w1; float* b1;
     char* w2; char* w2p; float* b2;
+    char* wqkvk;          // W_qkv for the Q/K/V tail of the previous layer's FFN kernel: fp32 columns in paired order (= wqkv in bf16 mode)
     char* w1k;            // W1 for the out-proj-fused FFN: fp32 columns in paired order (= w1 in bf16 mode)
     float *g1, *e1, *g2, *e2;
 };
@@ -211,6 +212,7 @@ struct PpgEngine {
     int lin_nt = 0;       // same for the linear/conv kernels
     int num_cus = 256;
     bool ffn_fused = true;
+    bool qkv_fused = true;   // next layer's Q/K/V projection as the tail of the fused FFN kernel (PPGS_AMD_QKV_FUSED=0: own kernel)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
@@ -241,6 +243,11 @@ struct PpgEngine {
             unsigned long long h[256];
             (void)hipDeviceSynchronize();
             if (hipMemcpy(h, ffn_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int i = 0; i < 6; ++i) {
+                    const unsigned long long* t = h + 192 + i * 8;
+                    if (t[0]) fprintf(stderr, "ffn qkv tail tile %d: wait %llu barrier %llu mfma %llu stores %llu dma %llu | total %llu\n", i + 4,
+                                      t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+                }
                 for (int w = 0; w < 4; ++w) {
                     const unsigned long long* t = h + 128 + w * 16;
                     fprintf(stderr, "ffn prologue wave %d:", w);
@@ -648,6 +655,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         e->ev_join.push_back(ev);
     }
     if (const char* v = getenv("PPGS_AMD_OP_FUSED")) e->op_fused = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->lin_dbg), 16 * 8192 * 8));
@@ -702,6 +710,12 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         if ((rc = paired(wts->out_proj_weight[l], H, H, &d.wo))) return rc;
         if ((rc = plain(wts->linear1_weight[l], F, H, &d.w1))) return rc;
         if ((rc = paired(wts->linear2_weight[l], H, F, &d.w2))) return rc;
+        d.wqkvk = d.wqkv;
+        if (e->sz == 4) {
+            const float* w = wts->in_proj_weight[l];
+            rc = upload_matrix(E, 3 * H, H, 3 * H, H, [&](int r, int c) { return w[(size_t)pair_row(r) * H + pair_row(c)]; }, &d.wqkvk);
+            if (rc) return rc;
+        }
         d.w1k = d.w1;
         if (e->sz == 4) {   // the fused prologue hands LN1's fp32 accumulators to phase A in paired K order
             const float* w = wts->linear1_weight[l];
@@ -851,9 +865,10 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, lnt, a, H / 256, s), "in-conv");
     }
     const int hg = H / e->KG;   // K-groups of a hidden-wide row
+    bool qkv_done = false;   // this layer's Q/K/V came out of the previous layer's FFN kernel
     for (int l = 0; l < c.num_layers; ++l) {
         const DevLayer& d = e->layers[l];
-        {
+        if (!qkv_done) {
             Timed t(e, PPG_K_QKV, s);
             LinearArgs a = base_args();
             a.act = act_x; a.lda_bytes = H * e->sz;
@@ -892,8 +907,15 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 a.splits = ws.ffn_splits;
                 a.partial = ws.ffn_splits > 1 ? reinterpret_cast<float*>(base + ws.part) : nullptr;
                 if (fuse_op) { a.ao = ao; a.Wo = d.wo; a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.W1 = d.w1k; }
+                qkv_done = fuse_op && e->qkv_fused && l + 1 < c.num_layers;
+                if (qkv_done) {
+                    const DevLayer& nx = e->layers[l + 1];
+                    a.Wq = nx.wqkvk; a.bq = nx.bqkv; a.qk_out = qk; a.vt_out = vt; a.vt_ld = ws.vt_ld;
+                    a.blk_win = grp.d_blk; a.win = grp.d_win;
+                }
                 LAUNCH_OK(ppg::launch_ffn(prec, a, ws.ffn_nt, s), "ffn");
             } else {
+                qkv_done = false;
                 LinearArgs a = base_args();
                 a.act = act_x; a.lda_bytes = H * e->sz;
                 a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;

@@ -210,13 +210,15 @@ __device__ __forceinline__ void lds_stream(const uint32_t (&fb)[L::VAR], USE use
 //   x1 is both the next GEMM's operand and, left in the accumulators that the
 //   FFN then adds to, the second residual).
 // MODE LN_NO_RESIDUAL: acc already contains the residual; stores like LN_EPILOGUE.
+// MODE LN_NO_RESIDUAL_KEEP: same input, result to X only and kept in acc (the
+//   next layer's Q/K/V projection follows in the same kernel, no bf16 copy needed).
 // lnp = [bias | gamma | beta], H floats each, in LDS: read from global per
 // (feature block, token block) these were 60 % of the epilogue's memory
 // instructions, all queueing behind the residual loads and the stores in the
 // CU's one address unit.  Loops run feature-block-outer so each parameter
 // vector is fetched once for all NT token blocks.
 // ---------------------------------------------------------------------------
-enum { LN_EPILOGUE = 0, LN_KEEP = 1, LN_NO_RESIDUAL = 2 };
+enum { LN_EPILOGUE = 0, LN_KEEP = 1, LN_NO_RESIDUAL = 2, LN_NO_RESIDUAL_KEEP = 3 };
 template <class P, int NB, int NT, int MODE>
 __device__ __forceinline__ void resln(
     f32x4 (&acc)[NB][NT], const float* lnp, float* X, char* Xb, int H,
@@ -239,7 +241,7 @@ __device__ __forceinline__ void resln(
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (MODE != LN_NO_RESIDUAL) {
+            if constexpr (MODE != LN_NO_RESIDUAL && MODE != LN_NO_RESIDUAL_KEEP) {
                 if (ok[t]) rv = *reinterpret_cast<const float4*>(xrow[t] + n);
             }
             acc[nb][t][0] += bv.x + rv.x;
@@ -276,12 +278,13 @@ __device__ __forceinline__ void resln(
             const float y1 = (acc[nb][t][1] - mean[t]) * rstd[t] * gv.y + ev.y;
             const float y2 = (acc[nb][t][2] - mean[t]) * rstd[t] * gv.z + ev.z;
             const float y3 = (acc[nb][t][3] - mean[t]) * rstd[t] * gv.w + ev.w;
-            if constexpr (MODE == LN_KEEP) {
-                acc[nb][t] = f32x4{y0, y1, y2, y3};
-            } else if (ok[t]) {
-                *reinterpret_cast<float4*>(xrow[t] + n) = make_float4(y0, y1, y2, y3);
-                if constexpr (P::kIsBF16)
-                    pair[t].put(Xb + ((size_t)(tok0 + 16 * t + idx) * H + (n & ~7)) * 2, nb & 1, y0, y1, y2, y3);
+            if constexpr (MODE == LN_KEEP || MODE == LN_NO_RESIDUAL_KEEP) acc[nb][t] = f32x4{y0, y1, y2, y3};
+            if constexpr (MODE != LN_KEEP) {
+                if (ok[t]) {
+                    *reinterpret_cast<float4*>(xrow[t] + n) = make_float4(y0, y1, y2, y3);
+                    if constexpr (P::kIsBF16 && MODE != LN_NO_RESIDUAL_KEEP)
+                        pair[t].put(Xb + ((size_t)(tok0 + 16 * t + idx) * H + (n & ~7)) * 2, nb & 1, y0, y1, y2, y3);
+                }
             }
         }
     }
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 // into the host-side packing of W2, see pack_w2 in ppg_engine.hip).
 // W1/W2 chunk tiles (32 KiB each) are staged global->regs->LDS.
 // ---------------------------------------------------------------------------
-template <class P, int NT, int NBH, bool OP>
+template <class P, int NT, int NBH, bool OP, bool QKV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = NBH * 16;
@@ -798,6 +801,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto stage_w2 = [&](int c) {
         stage_tile<H, ROW2, 4>(a.W2p + (size_t)hidden_chunk(c) * ROW2, (size_t)a.F * P::kBytes, smem + 65536 + (c & 1) * 32768, wave, lane);
     };
+    // QKV: transposed-V column (lane group 0) of each of the wave's 16-token
+    // blocks, wave-uniform, -1 = padding block; see linear_kernel
+    int vw[NT], vcol[NT];
+    if constexpr (QKV) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int mb = tok0 + 16 * t;
+            vw[t] = mb < a.M ? a.blk_win[mb >> 4] : -1;
+            vcol[t] = -1;
+            if (vw[t] >= 0) {
+                const int ttb = mb - a.win[vw[t]].tok_off;
+                if constexpr (P::kIsBF16) vcol[t] = a.win[vw[t]].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
+                else vcol[t] = a.win[vw[t]].vt_off + ttb;
+            }
+        }
+    }
     // OP: the W1 double buffer first carries the H/HC tiles of W_o
     constexpr int OT = H / HC;
     static_assert(OT % 2 == 0, "W_o tiles must leave the W1 buffers in phase");
@@ -820,6 +839,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* lnp1 = lnp2 + 3 * H;
     stage_params(lnp2, H, tid, a.b2, a.gamma, a.beta);
     if constexpr (OP) stage_params(lnp1, H, tid, a.bo, a.g1, a.e1);
+    float* ldsbq = lnp1 + 3 * H;          // QKV: the next layer's in_proj bias, 3H floats
+    if constexpr (QKV) stage_params(ldsbq, H, tid, a.bq, a.bq + H, a.bq + 2 * H);
 
     // B fragments of the wave's tokens: x (bf16 copy / fp32 X), or with OP the
     // attention output, replaced by LN1's result below
@@ -1007,7 +1028,146 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (OP: nothing derived from the lane coordinates before the chunk loop may stay live across it)
     int tok0e = tok0, idxe = idx, ge = g;
     if constexpr (OP) asm volatile("" : "+s"(tok0e), "+v"(idxe), "+v"(ge));
-    resln<P, NBH, NT, OP ? LN_NO_RESIDUAL : LN_EPILOGUE>(yacc, lnp2, a.X, a.Xb, H, tok0e, a.M, idxe, ge);
+    if constexpr (!QKV) {
+        resln<P, NBH, NT, OP ? LN_NO_RESIDUAL : LN_EPILOGUE>(yacc, lnp2, a.X, a.Xb, H, tok0e, a.M, idxe, ge);
+    } else {
+        // ---- the next layer's Q/K/V projection on x2 = LN2(...) ----------------
+        // x2 is in the accumulators in paired feature order, i.e. (as in the OP
+        // prologue) already the B fragments of a GEMM over the hidden dimension.
+        // W_qkv streams through the four now idle 32 KiB weight buffers, three
+        // tiles of HC rows ahead; every tile yields HC finished features that are
+        // stored at once (Q/K rows: 16-byte stores; V tiles: swapped operands,
+        // transposed store, see linear_kernel).  With one wave per SIMD the
+        // stores are issue-bound (~280 cycles each, measured) and do not overlap
+        // the MFMAs -- interleaving them into the next tile's stream changes
+        // nothing -- but the tail still beats the stand-alone projection kernel:
+        // no activation reload, no second pass over X as bf16.
+        static_assert(OP, "the Q/K/V tail needs the residual-in-accumulator form");
+        constexpr int QT = 3 * H / HC;                     // W_qkv tiles
+        constexpr int PIECES = 32768 / 1024 / 4;           // DMA instructions per tile and wave
+        // workgroup b walks the tiles from its own offset (the stores of the
+        // lockstepped workgroups then spread over the Q|K row instead of all
+        // hitting one 128-byte column)
+        const int qrot = blockIdx.x % QT;
+        auto tile_of = [&](int i) { const int r = i + qrot; return r >= QT ? r - QT : r; };
+        auto stage_q = [&](int i) {
+            stage_tile<HC, ROW1, 4>(a.Wq + (size_t)tile_of(i) * 32768, (size_t)ROW1, smem + (i & 3) * 32768, wave, lane);
+        };
+        // the chunk loop ended on a barrier: all four buffers are free
+        stage_q(0); stage_q(1); stage_q(2);
+        resln<P, NBH, NT, LN_NO_RESIDUAL_KEEP>(yacc, lnp2, a.X, nullptr, H, tok0e, a.M, idxe, ge);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int kg = 0; kg < XG; ++kg) {
+                if constexpr (P::kIsBF16) {
+                    xf[kg][t] = u32x4{pack_bf16x2(yacc[2 * kg][t][0], yacc[2 * kg][t][1]), pack_bf16x2(yacc[2 * kg][t][2], yacc[2 * kg][t][3]),
+                                      pack_bf16x2(yacc[2 * kg + 1][t][0], yacc[2 * kg + 1][t][1]), pack_bf16x2(yacc[2 * kg + 1][t][2], yacc[2 * kg + 1][t][3])};
+                } else {
+                    xf[kg][t] = u32x4{__float_as_uint(yacc[kg][t][0]), __float_as_uint(yacc[kg][t][1]),
+                                      __float_as_uint(yacc[kg][t][2]), __float_as_uint(yacc[kg][t][3])};
+                }
+            }
+        }
+        bool full_rows = true, full_cols = true;           // every store below is really issued: counted waits are exact
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            full_rows = full_rows && tok0 + 16 * t < a.M;
+            full_cols = full_cols && vcol[t] >= 0;
+        }
+        const int v_start = 2 * H;
+#ifdef PPG_FFN_TIMING
+        auto qstamp = [&](int i, int k) {
+            if (a.dbg && blockIdx.x == 0 && lane == 0 && wave == 0 && i >= 4 && i < 10) a.dbg[192 + (i - 4) * 8 + k] = __builtin_amdgcn_s_memtime();
+        };
+#else
+        auto qstamp = [&](int, int) {};
+#endif
+        for (int i = 0; i < QT; ++i) {
+            qstamp(i, 0);
+            // Tile i's DMA is older than: the DMA of tiles i+1, i+2 and the stores of
+            // tiles i-2, i-1 (order per iteration: wait, barrier, MFMAs, stores, DMA
+            // of tile i+3).  Q/K tiles store HB/2 * NT times per wave, V tiles at
+            // least as often, so that many operations may stay in flight.
+            constexpr int NSTORE = (HB / 2 > 0 ? HB / 2 : 1) * NT;
+            if (full_rows && full_cols && i >= 2 && i + 2 < QT)
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PIECES + 2 * NSTORE) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            qstamp(i, 1);
+            __syncthreads();
+            qstamp(i, 2);
+            const int n0 = tile_of(i) * HC;
+            const bool swap = n0 >= v_start;
+            f32x4 acc[HB][NT];
+            uint32_t fba[LA::VAR];
+            LA::bases(lds0 + (i & 3) * 32768, idx, g, fba);
+            auto mfmas = [&](auto swap_tag) {
+                constexpr bool SWAP = decltype(swap_tag)::value;
+                lds_stream<LA, RA, DEPTH>(fba, [&](auto ic, const u32x4& wf) {
+                    constexpr int f = decltype(ic)::value;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (f / HB == 0) {
+                            if constexpr (SWAP) P::mma0(acc[f % HB][t], xf[0][t], wf);
+                            else P::mma0(acc[f % HB][t], wf, xf[0][t]);
+                        } else {
+                            if constexpr (SWAP) P::mma(acc[f % HB][t], xf[f / HB][t], wf);
+                            else P::mma(acc[f % HB][t], wf, xf[f / HB][t]);
+                        }
+                    }
+                });
+            };
+            if (!swap) {
+                mfmas(std::false_type{});
+                qstamp(i, 3);
+                PairStore<P> pair[NT];
+#pragma unroll
+                for (int nb = 0; nb < HB; ++nb) {
+                    const int gb = n0 / 16 + nb;                     // 16-row block index in W_qkv
+                    const int n = pair_feature(gb, g);
+                    const float4 bv = *reinterpret_cast<const float4*>(ldsbq + n);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int m = tok0 + 16 * t + idx;
+                        if (tok0 + 16 * t >= a.M) continue;          // wave-uniform
+                        pair[t].put(a.qk_out + ((size_t)m * 2 * H + (n & ~7)) * P::kBytes, gb & 1,
+                                    acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
+                                    acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
+                    }
+                }
+            } else {
+                mfmas(std::true_type{});
+                qstamp(i, 3);
+                bool done_with_previous = false;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (done_with_previous) { done_with_previous = false; continue; }
+                    if (vw[t] < 0) continue;
+                    constexpr int kLast = NT - 1;
+                    const int tn = t < kLast ? t + 1 : t;
+                    const bool paired = P::kIsBF16 && t < kLast && vw[tn] == vw[t] && (vcol[t] & 4) == 0;
+#pragma unroll
+                    for (int nb = 0; nb < HB; ++nb) {
+                        const int row = n0 + nb * 16 + idx;
+                        const float bv = ldsbq[pair_row(row)];
+                        char* dst = a.vt_out + ((size_t)(row - v_start) * a.vt_ld + vcol[t] + (P::kIsBF16 ? 8 : 4) * g) * P::kBytes;
+                        if (paired) {
+                            *reinterpret_cast<u32x4*>(dst) = u32x4{
+                                pack_bf16x2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), pack_bf16x2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
+                                pack_bf16x2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv), pack_bf16x2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv)};
+                        } else {
+                            store4<P>(dst, acc[nb][t][0] + bv, acc[nb][t][1] + bv, acc[nb][t][2] + bv, acc[nb][t][3] + bv);
+                        }
+                    }
+                    done_with_previous = paired;
+                }
+            }
+            qstamp(i, 4);
+            if (i + 3 < QT) stage_q(i + 3);       // into the buffer tile i-1 was read from (all waves passed this iteration's barrier)
+            qstamp(i, 5);
+        }
+    }
 }
 
 // Second half of the split-hidden FFN: X <- LN(X + b2 + sum_s partial[s]).
@@ -1330,11 +1490,11 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
     return hipErrorInvalidValue;
 }
 
-template <class P, int NT, int NBH, bool OP>
+template <class P, int NT, int NBH, bool OP, bool QKV>
 hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const dim3 blocks((a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
-    auto kern = ffn_kernel<P, NT, NBH, OP>;
-    const size_t lds = 131072 + (size_t)a.F * 4 + 6 * (size_t)a.H * 4;
+    auto kern = ffn_kernel<P, NT, NBH, OP, QKV>;
+    const size_t lds = 131072 + (size_t)a.F * 4 + (QKV ? 9 : 6) * (size_t)a.H * 4;
     static size_t configured = 0;            // once per process and size: not a stream operation
     if (configured < lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1348,14 +1508,14 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <class P, bool OP>
+template <class P, bool OP, bool QKV>
 hipError_t launch_ffn_op(const FfnArgs& a, int nt, hipStream_t s) {
     if (a.H == 256) {
-        if (nt == 1) return launch_ffn_t<P, 1, 16, OP>(a, s);
-        if constexpr (P::kIsBF16) if (nt == 3) return launch_ffn_t<P, 3, 16, OP>(a, s);
-        return launch_ffn_t<P, 2, 16, OP>(a, s);
+        if (nt == 1) return launch_ffn_t<P, 1, 16, OP, QKV>(a, s);
+        if constexpr (P::kIsBF16) if (nt == 3) return launch_ffn_t<P, 3, 16, OP, QKV>(a, s);
+        return launch_ffn_t<P, 2, 16, OP, QKV>(a, s);
     }
-    if (a.H == 512) return launch_ffn_t<P, 1, 32, OP>(a, s);
+    if (a.H == 512) return launch_ffn_t<P, 1, 32, OP, QKV>(a, s);
     return hipErrorInvalidValue;
 }
 
@@ -1363,9 +1523,11 @@ template <class P>
 hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
     if (a.Wo != nullptr) {
         if (a.partial != nullptr) return hipErrorInvalidValue;   // every split would redo the out-projection
-        return launch_ffn_op<P, true>(a, nt, s);
+        if (a.Wq != nullptr) return launch_ffn_op<P, true, true>(a, nt, s);
+        return launch_ffn_op<P, true, false>(a, nt, s);
     }
-    return launch_ffn_op<P, false>(a, nt, s);
+    if (a.Wq != nullptr) return hipErrorInvalidValue;            // the Q/K/V tail comes with the fused out-projection only
+    return launch_ffn_op<P, false, false>(a, nt, s);
 }
 
 template <class P>
