@@ -103,7 +103,11 @@ def pmc_traffic(kernel='ffn_kernel'):
     if not files:
         return None
     fetch = write = None
-    for line in open(files[-1]):
+    lines = [line for line in open(files[-1]) if line.startswith(kernel)]
+    # several variants of the kernel in one run: the one with the Q/K/V tail
+    # (4 of the 5 launches of a step) is the one the roofline line describes
+    tail = [line for line in lines if 'true, true>' in line]
+    for line in tail or lines:
         if line.startswith(kernel):
             m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
             fetch = float(m.group(1)) if m else fetch
@@ -184,8 +188,16 @@ def main():
         # (FFN 2*2*H*F per processed frame; the attention
         # out-projection's 2*H*H ride along when the engine fuses it into the
         # same kernel -- then no separate out-proj launch shows up)
+        # and so does the NEXT layer's Q/K/V projection (6*H*H) in all but the last
+        # layer's launch when that is fused as the kernel's tail (then only layer
+        # 0 launches a Q/K/V kernel of its own); flops_per_launch is the mean
+        # over the five launches of a step
+        layers = 5
         op_fused = kernels['outproj_ln'][1] == 0
-        flops_per_frame = 4.0 * hidden * ffn + (2.0 * hidden * hidden if op_fused else 0.0)
+        qkv_own = kernels['qkv'][1] / breakdown_steps / launches_per_layer    # stand-alone Q/K/V launches per step
+        qkv_fused_layers = max(layers - qkv_own, 0.0) if op_fused else 0.0
+        flops_per_frame = (4.0 * hidden * ffn + (2.0 * hidden * hidden if op_fused else 0.0)
+                           + 6.0 * hidden * hidden * qkv_fused_layers / layers)
         ffn_flops = flops_per_frame * info.processed_frames / launches_per_layer
         ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_launches, 1)) / 1e12
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_FP32_TFLOPS
@@ -212,7 +224,8 @@ def main():
                 'parallelism': f'utterance-sharded x{world}, no data-path collective',
             },
             'roofline': {
-                'kernel': ('ffn_kernel (fused out-proj+residual+LN1, W1+ReLU+W2+residual+LN2)' if op_fused
+                'kernel': ('ffn_kernel (fused out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
+                           + (', next layer Q/K/V)' if qkv_fused_layers else ')') if op_fused
                            else 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)'),
                 'bound': 'mfma',
                 'achieved': ffn_tflops,
