@@ -206,6 +206,44 @@ def test_unfused_ffn_path_agrees(monkeypatch):
     assert np.abs(a - b).max() < 2e-5
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
+    """Batches above ~6 k token rows run each layer as attention + ONE kernel
+    (out-proj + LN1 + FFN + LN2 + next layer's Q/K/V).  Ragged 700-frame items
+    give windows of 500 + 300 frames: 19-block windows put the following window
+    at an odd 16-token block (unpaired V^T stores), padding blocks and exhausted
+    windows are present.  Checked against the CPU oracle and against the same
+    engine with the fusions switched off."""
+    state = W.seeded_state_dict(seed=99)
+    gen = torch.Generator().manual_seed(17)
+    batch, frames = 24, 700
+    lengths = [700, 700, 655, 700, 513, 700, 402, 700, 700, 311, 700, 700,
+               700, 99, 700, 700, 500, 700, 700, 641, 700, 17, 700, 700]
+    feats = torch.randn(batch, 80, frames, generator=gen).half()
+    _, info = E.plan_windows(batch, frames, lengths)
+    assert info.tokens > 6144 and info.skipped_windows > 0
+    fused = E.Engine(state, 0, precision)
+    out = run(fused, feats, lengths)
+    monkeypatch.setenv('PPGS_AMD_OP_FUSED', '0')
+    monkeypatch.setenv('PPGS_AMD_QKV_FUSED', '0')
+    pieces = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_OP_FUSED')
+    monkeypatch.setenv('PPGS_AMD_QKV_FUSED', '0')
+    no_tail = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_QKV_FUSED')
+    ref = O.from_features(state, feats, torch.tensor(lengths)).numpy()
+    out_pieces = run(pieces, feats, lengths)
+    out_no_tail = run(no_tail, feats, lengths)
+    # tolerances: fp32 = the parity bar; bf16 = what test_bf16_mode allows
+    tol = FP32_TOL if precision == 'fp32' else BF16_TOL
+    same = 2e-5 if precision == 'fp32' else 1e-2      # bf16: x1 is rounded at a different point when kept in registers
+    assert np.abs(out - ref).max() < tol
+    assert np.abs(out - out_pieces).max() < same
+    assert np.abs(out - out_no_tail).max() < same
+    for b, n in enumerate(lengths):
+        assert np.allclose(out[b, :, n:], 1 / 40)
+
+
 def test_bf16_mode(golden):
     g = golden('g2_single_window')
     engine, _ = eng(precision='bf16')
