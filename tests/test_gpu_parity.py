@@ -244,6 +244,21 @@ def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
         assert np.allclose(out[b, :, n:], 1 / 40)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_fused_layer_kernel_hidden_512(precision):
+    """The w2v2fb-shaped network (768 -> 512) through the fused layer kernel
+    (32-row weight tiles, 48 Q/K/V tiles, one 16-token block per wave)."""
+    state = W.seeded_state_dict(seed=31, input_channels=768, hidden_channels=512)
+    gen = torch.Generator().manual_seed(4)
+    lengths = [600, 600, 471, 600, 333, 600]
+    feats = torch.randn(6, 768, 600, generator=gen).half()
+    _, info = E.plan_windows(6, 600, lengths)
+    assert info.tokens > 2048                        # above the split-hidden regime
+    out = run(E.Engine(state, 0, precision), feats, lengths)
+    ref = O.from_features(state, feats, torch.tensor(lengths)).numpy()
+    assert np.abs(out - ref).max() < (FP32_TOL if precision == 'fp32' else BF16_TOL)
+
+
 def test_bf16_mode(golden):
     g = golden('g2_single_window')
     engine, _ = eng(precision='bf16')

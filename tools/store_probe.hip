@@ -63,6 +63,26 @@ void run(const char* name, char* out, int M, int ld, int passes) {
     printf("%-44s %7.1f us  %6.2f TB/s\n", name, us, mb / us);
 }
 
+// one workgroup per CU (100 KiB of LDS each), 4 waves, like the fused layer kernel's tail
+template <int PATTERN>
+void run_sparse(const char* name, char* out, int M, int ld, int passes) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    dim3 grid(M / 128, passes);
+    auto kern = probe<PATTERN>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 102400);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), 102400, 0, out, M, ld, 1);
+    hipEventRecord(a);
+    const int iters = 20;
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), 102400, 0, out, M, ld, 1);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double us = ms * 1e3 / iters, mb = (double)M * 512 * passes / 1e6;
+    printf("%-44s %7.1f us  %6.2f TB/s\n", name, us, mb / us);
+}
+
 int main() {
     const int M = 40960, ld = 1536;
     char* out;
@@ -73,6 +93,11 @@ int main() {
     run<4>("8 rows x 128 B per instruction", out, M, ld, 3);
     run<3>("4 rows x 256 B per instruction", out, M, ld, 3);
     run<1>("2 rows x 512 B per instruction", out, M, ld, 3);
+    printf("one workgroup (4 waves) per CU:\n");
+    run_sparse<0>("acc layout  8 B/lane (16 rows x 32 B)", out, M, ld, 3);
+    run_sparse<2>("acc layout 16 B/lane (16 rows x 64 B)", out, M, ld, 3);
+    run_sparse<4>("8 rows x 128 B per instruction", out, M, ld, 3);
+    run_sparse<1>("2 rows x 512 B per instruction", out, M, ld, 3);
     hipFree(out);
     return 0;
 }
