@@ -838,7 +838,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
 
     // V^T padding columns and the K rows past the last token are read (masked)
     // by the attention tiles: keep them finite.
-    HIP_OK(hipMemsetAsync(vt, 0, (size_t)H * ws.vt_ld * e->sz, s));
+    LAUNCH_OK(ppg::launch_vt_pad(vt, ws.vt_ld, (int)e->sz, H, grp.d_win, (int)grp.windows.size(), grp.vt_tokens, s), "vt-pad");
     HIP_OK(hipMemsetAsync(qk + (size_t)M * 2 * H * e->sz, 0, (size_t)64 * 2 * H * e->sz, s));
 
     {

@@ -441,6 +441,29 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     }
 }
 
+// Zero the columns of the transposed-V buffer that no projection writes but the
+// attention tiles read (masked, p = 0 -- but 0 x NaN would poison the sum): the
+// odd 16-column tail of windows whose padded length is not a multiple of 32,
+// and the slack behind the last window.  One workgroup per window, + 1.
+__global__ __launch_bounds__(256) void vt_pad_kernel(char* vt, int vt_ld, int elem_bytes, int rows,
+                                                      const PpgWindow* win, int nwin, int vt_tokens) {
+    int col, count;
+    if ((int)blockIdx.x < nwin) {
+        const PpgWindow w = win[blockIdx.x];
+        const int r16 = (w.frames + 15) & ~15, r32 = (w.frames + 31) & ~31;
+        col = w.vt_off + r16;
+        count = r32 - r16;
+    } else {
+        col = vt_tokens;
+        count = vt_ld - vt_tokens;
+    }
+    const int chunks = count * elem_bytes / 16;          // 16-column steps: whole 16-byte pieces
+    for (int i = threadIdx.x; i < rows * chunks; i += 256) {
+        const int r = i / chunks, c = i - r * chunks;
+        *reinterpret_cast<uint4*>(vt + ((size_t)r * vt_ld + col) * elem_bytes + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 __global__ void fill_kernel(float* p, size_t n, float v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1552,6 +1575,11 @@ hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s) {
     dim3 grid((a.M + 63) / 64, (a.Cp + 31) / 32);
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(gather_kernel<PrecBF16>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gather_kernel<PrecF32>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_vt_pad(char* vt, int vt_ld, int elem_bytes, int rows, const PpgWindow* win, int nwin, int vt_tokens, hipStream_t s) {
+    hipLaunchKernelGGL(vt_pad_kernel, dim3(nwin + 1), dim3(256), 0, s, vt, vt_ld, elem_bytes, rows, win, nwin, vt_tokens);
     return hipGetLastError();
 }
 

@@ -224,6 +224,9 @@ def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
     assert info.tokens > 6144 and info.skipped_windows > 0
     fused = E.Engine(state, 0, precision)
     out = run(fused, feats, lengths)
+    for workspace in fused._workspaces.values():       # nothing may depend on what the scratch held
+        workspace.view(torch.int16).fill_(-1)
+    assert np.array_equal(out, run(fused, feats, lengths))
     monkeypatch.setenv('PPGS_AMD_OP_FUSED', '0')
     monkeypatch.setenv('PPGS_AMD_QKV_FUSED', '0')
     pieces = E.Engine(state, 0, precision)
@@ -242,6 +245,23 @@ def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
     assert np.abs(out - out_no_tail).max() < same
     for b, n in enumerate(lengths):
         assert np.allclose(out[b, :, n:], 1 / 40)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_poisoned_workspace(precision):
+    """Nothing in the scratch workspace is read before it is written: the
+    caller's buffer may hold anything (here: NaN bit patterns).  Windows of 40
+    and 300 frames have odd numbers of 16-token blocks, i.e. V^T pad columns."""
+    engine, state = eng(seed=5, precision=precision)
+    gen = torch.Generator().manual_seed(12)
+    lengths = [700, 40, 300, 513]
+    feats = torch.randn(4, 80, 700, generator=gen).half()
+    clean = run(engine, feats, lengths)
+    for workspace in engine._workspaces.values():
+        workspace.view(torch.int16).fill_(-1)          # 0xffff.. = NaN as bf16, fp16 and fp32
+    dirty = run(engine, feats, lengths)
+    assert np.isfinite(dirty).all()
+    assert np.array_equal(clean, dirty)
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
