@@ -44,12 +44,25 @@ __device__ __forceinline__ int swz(int row, int p) {
 }
 
 
+// LDS byte address (low 32 bits of the flat address of a __shared__ object)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS address is the
 // wave-uniform base + lane*16, the global address is per lane.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)gsrc,
         (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// The same DMA in its scalar-base form: wave-uniform 64-bit base in SGPRs + a
+// 32-bit per-lane offset that is never rewritten.  hipcc expands the builtin
+// to a 64-bit VALU add into one VGPR pair per piece, reused by the next piece,
+// so every piece waits for the previous one to have read its address.
+__device__ __forceinline__ void glds16_saddr(const char* uniform_base, uint32_t lane_off, uint32_t lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_off), "s"(uniform_base), "s"(lds_wave_addr) : "memory", "m0");
 }
 
 // Stage a [ROWS][ROW_BYTES] tile (global row stride gstride) into LDS by DMA.
@@ -89,7 +102,7 @@ struct TileDma {
             const int piece = i * NWAVES + wave;
             if (PIECES % NWAVES == 0 || piece < PIECES) {
                 const size_t base = (size_t)(piece / PERIOD) * ROWS_PER_PERIOD * gstride;
-                glds16(gsrc + base + lane_off[i % V], lds + piece * 1024);
+                glds16_saddr(gsrc + base, lane_off[i % V], lds_addr(lds) + piece * 1024);
             }
         }
     }
@@ -105,10 +118,6 @@ __device__ __forceinline__ void dma_wait_barrier() {
     __syncthreads();
 }
 
-// LDS byte address (low 32 bits of the flat address of a __shared__ object)
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
 
 // ds_read_b128 the compiler does not schedule or count: it sinks ordinary LDS
 // loads next to their first use and waits lgkmcnt(0) after every one or two
