@@ -252,4 +252,13 @@ struct GatherArgs {
     const int* blk_win;
     const PpgWindow* win;
     int M;
+    // scratch areas nobody writes but the attention tiles read (masked): zeroed by
+    // the extra blockIdx.y row of the gather launch
+    char* vt;                 // transposed V [vt_rows][vt_ld] elements
+    int vt_ld;
+    int vt_rows;              // H
+    int vt_tokens;            // columns in use; the rest of a row is slack
+    int nwin;
+    char* qk_slack;           // the rows behind the last token of the q|k buffer
+    int qk_slack_bytes;       // multiple of 16
 };

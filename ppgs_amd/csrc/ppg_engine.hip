@@ -836,17 +836,16 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     const int lnt = forced ? e->lin_nt : std::min(nt, 2);
     const int lnt_ln = forced ? e->lin_nt : 1;
 
-    // V^T padding columns and the K rows past the last token are read (masked)
-    // by the attention tiles: keep them finite.
-    LAUNCH_OK(ppg::launch_vt_pad(vt, ws.vt_ld, (int)e->sz, H, grp.d_win, (int)grp.windows.size(), grp.vt_tokens, s), "vt-pad");
-    HIP_OK(hipMemsetAsync(qk + (size_t)M * 2 * H * e->sz, 0, (size_t)64 * 2 * H * e->sz, s));
-
     {
         Timed t(e, PPG_K_GATHER, s);
         GatherArgs g{};
         g.feats = features; g.dtype = feature_dtype; g.C = c.input_channels; g.T = frames;
         g.overlap = c.chunk_overlap; g.xw = xw; g.Cp = e->Cp;
         g.blk_win = grp.d_blk; g.win = grp.d_win; g.M = M;
+        // V^T padding columns and the K rows past the last token are read (masked)
+        // by the attention tiles: the same launch keeps them finite
+        g.vt = vt; g.vt_ld = ws.vt_ld; g.vt_rows = H; g.vt_tokens = grp.vt_tokens; g.nwin = (int)grp.windows.size();
+        g.qk_slack = qk + (size_t)M * 2 * H * e->sz; g.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
         LAUNCH_OK(ppg::launch_gather(prec, g, s), "gather");
     }
     auto base_args = [&]() {

@@ -404,6 +404,36 @@ __device__ __forceinline__ void ln_keep(
 // ---------------------------------------------------------------------------
 template <class P>
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
+    if (blockIdx.y == gridDim.y - 1) {
+        // Housekeeping row: zero what no kernel writes but the attention tiles read
+        // (masked, p = 0 -- but 0 x NaN would poison the sum): the odd 16-column
+        // tail of windows whose padded length is not a multiple of 32, the slack
+        // behind the last V^T column, and the q|k rows behind the last token.
+        constexpr int kBytes = P::kBytes;
+        for (int job = blockIdx.x; job <= a.nwin + 1; job += gridDim.x) {
+            if (job == a.nwin + 1) {
+                for (int i = threadIdx.x; i < a.qk_slack_bytes / 16; i += 256)
+                    reinterpret_cast<uint4*>(a.qk_slack)[i] = make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
+            int col, count;
+            if (job < a.nwin) {
+                const PpgWindow w = a.win[job];
+                const int r16 = (w.frames + 15) & ~15, r32 = (w.frames + 31) & ~31;
+                col = w.vt_off + r16;
+                count = r32 - r16;
+            } else {
+                col = a.vt_tokens;
+                count = a.vt_ld - a.vt_tokens;
+            }
+            const int chunks = count * kBytes / 16;      // 16-column steps: whole 16-byte pieces
+            for (int i = threadIdx.x; i < a.vt_rows * chunks; i += 256) {
+                const int r = i / chunks, c = i - r * chunks;
+                *reinterpret_cast<uint4*>(a.vt + ((size_t)r * a.vt_ld + col) * kBytes + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        return;
+    }
     __shared__ float tile[32][65];
     const int tok0 = blockIdx.x * 64;
     const int c0 = blockIdx.y * 32;
@@ -447,29 +477,6 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
                 else *dst = v;
             }
         }
-    }
-}
-
-// Zero the columns of the transposed-V buffer that no projection writes but the
-// attention tiles read (masked, p = 0 -- but 0 x NaN would poison the sum): the
-// odd 16-column tail of windows whose padded length is not a multiple of 32,
-// and the slack behind the last window.  One workgroup per window, + 1.
-__global__ __launch_bounds__(256) void vt_pad_kernel(char* vt, int vt_ld, int elem_bytes, int rows,
-                                                      const PpgWindow* win, int nwin, int vt_tokens) {
-    int col, count;
-    if ((int)blockIdx.x < nwin) {
-        const PpgWindow w = win[blockIdx.x];
-        const int r16 = (w.frames + 15) & ~15, r32 = (w.frames + 31) & ~31;
-        col = w.vt_off + r16;
-        count = r32 - r16;
-    } else {
-        col = vt_tokens;
-        count = vt_ld - vt_tokens;
-    }
-    const int chunks = count * elem_bytes / 16;          // 16-column steps: whole 16-byte pieces
-    for (int i = threadIdx.x; i < rows * chunks; i += 256) {
-        const int r = i / chunks, c = i - r * chunks;
-        *reinterpret_cast<uint4*>(vt + ((size_t)r * vt_ld + col) * elem_bytes + c * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -1581,14 +1588,9 @@ namespace ppg {
 int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }
 
 hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s) {
-    dim3 grid((a.M + 63) / 64, (a.Cp + 31) / 32);
+    dim3 grid((a.M + 63) / 64, (a.Cp + 31) / 32 + 1);       // + the housekeeping row
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(gather_kernel<PrecBF16>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gather_kernel<PrecF32>, grid, dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_vt_pad(char* vt, int vt_ld, int elem_bytes, int rows, const PpgWindow* win, int nwin, int vt_tokens, hipStream_t s) {
-    hipLaunchKernelGGL(vt_pad_kernel, dim3(nwin + 1), dim3(256), 0, s, vt, vt_ld, elem_bytes, rows, win, nwin, vt_tokens);
     return hipGetLastError();
 }
 

@@ -12,8 +12,7 @@ int attn_query_tile(int head_dim);   // queries per attention workgroup
 
 hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
-// zero the never-written columns of the transposed-V buffer (window tails, end slack)
-hipError_t launch_vt_pad(char* vt, int vt_ld, int elem_bytes, int rows, const PpgWindow* win, int nwin, int vt_tokens, hipStream_t s);
+
 hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s);
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
