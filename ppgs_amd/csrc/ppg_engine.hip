@@ -861,6 +861,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
         a.total_groups = e->in_total_groups;
         a.W = e->w_in; a.bias = e->b_in; a.N = H; a.pe = e->pe;
+        if (e->lin_dbg_class == PPG_K_INCONV) a.dbg = e->lin_dbg;
         LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, lnt, a, H / 256, s), "in-conv");
     }
     const int hg = H / e->KG;   // K-groups of a hidden-wide row
@@ -937,6 +938,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.total_groups = e->out_total_groups;
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
+        if (e->lin_dbg_class == PPG_K_OUTCONV_SOFTMAX) a.dbg = e->lin_dbg;
         LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, lnt_ln, a, 1, s), "out-conv+softmax");
     }
     return PPG_OK;
