@@ -213,6 +213,7 @@ struct PpgEngine {
     int num_cus = 256;
     bool ffn_fused = true;
     bool qkv_fused = true;   // next layer's Q/K/V projection as the tail of the fused FFN kernel (PPGS_AMD_QKV_FUSED=0: own kernel)
+    bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
@@ -365,6 +366,16 @@ void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) 
             nt = max_nt;
             while (splits * 2 <= chunks / 2 && tiles_max_nt * splits * 2 <= e->num_cus) splits *= 2;
         }
+    }
+    // mixed tiling (160-token workgroups, ppg_kernels.hip ffn_mixed_kernel): 2.5 blocks of
+    // MFMA work per wave and chunk instead of nt; worth it when it saves a round or
+    // shortens the one round there is (C2: 256 workgroups on 256 CUs instead of 214 larger ones)
+    if (splits == 1 && e->ffn_mixed && e->ffn_fused && e->op_fused && e->ffn_nt == 0 &&
+        e->cfg.precision == PPG_PRECISION_BF16 && e->cfg.hidden_channels == 256) {
+        const int blocks_nt = (M + 64 * nt - 1) / (64 * nt), blocks_mixed = (M + 159) / 160;
+        const double rounds_nt = (blocks_nt + e->num_cus - 1) / e->num_cus;
+        const double rounds_mixed = (blocks_mixed + e->num_cus - 1) / e->num_cus;
+        if (rounds_mixed * 2.5 < rounds_nt * nt) nt = ppg::kFfnMixedTiling;
     }
     *nt_out = nt;
     *splits_out = splits;
@@ -655,6 +666,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         e->ev_join.push_back(ev);
     }
     if (const char* v = getenv("PPGS_AMD_OP_FUSED")) e->op_fused = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_FFN_MIXED")) e->ffn_mixed = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);

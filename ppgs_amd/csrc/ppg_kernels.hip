@@ -61,8 +61,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // to a 64-bit VALU add into one VGPR pair per piece, reused by the next piece,
 // so every piece waits for the previous one to have read its address.
 __device__ __forceinline__ void glds16_saddr(const char* uniform_base, uint32_t lane_off, uint32_t lds_wave_addr) {
+    // (readfirstlane: free where the compiler already knows the value is wave-uniform, and the
+    // only way to get SGPR operands where it does not -- both bodies of ffn_mixed_kernel)
+    const uint64_t b = reinterpret_cast<uint64_t>(uniform_base);
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(lane_off), "s"(uniform_base), "s"(lds_wave_addr) : "memory", "m0");
+                 :: "v"(lane_off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave_addr)) : "memory", "m0");
 }
 
 // Stage a [ROWS][ROW_BYTES] tile (global row stride gstride) into LDS by DMA.
@@ -320,9 +325,9 @@ __device__ __forceinline__ void stage_params(float* lds, int H, int tid, const f
 // (unpinned, it spills most of the accumulators to scratch while they are
 // being computed and the chunk loop runs 15 % slower; pinning xf as well costs
 // 12 % -- measured, PPG_FFN_TIMING).
-template <class P, int NB, int NT, int XG>
+template <class P, int NB, int NT, int XG, int NTX>
 __device__ __forceinline__ void ln_keep(
-    f32x4 (&acc)[NB][NT], u32x4 (&xf)[XG][NT], const float* lnp, const float* X, int H,
+    f32x4 (&acc)[NB][NT], u32x4 (&xf)[XG][NTX], const float* lnp, const float* X, int H,
     int tok0, int M, int idx, int g)
 {
 #pragma unroll
@@ -810,9 +815,20 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 // into the host-side packing of W2, see pack_w2 in ppg_engine.hip).
 // W1/W2 chunk tiles (32 KiB each) are staged global->regs->LDS.
 // ---------------------------------------------------------------------------
-template <class P, int NT, int NBH, bool OP, bool QKV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_kernel(FfnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The kernel body for one wave.  NTB = 16-token blocks the wave OWNS (their y
+// accumulators, LayerNorms, Q/K/V tail), NTA = blocks whose phase A it computes.
+// ROLE 0: NTA == NTB, the plain kernel.  ROLE 1 / 2 (ffn_mixed_kernel): an
+// owner of 3 blocks lets its partner wave (owner of 2) compute the phase A of
+// its third block, so that both run 5 block-phases per chunk -- h of that
+// block travels partner -> owner through LDS once per chunk, its x1 fragments
+// owner -> partner once per launch.
+template <class P, int NTA, int NTB, int NBH, bool OP, bool QKV, int ROLE>
+__device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int tok0) {
+    constexpr int NT = NTB;                         // token blocks of everything outside the chunk loop
+    constexpr int NTX = NTA > NTB ? NTA : NTB;      // operand fragment sets held
+    constexpr int NTL = NTA < NTB ? NTA : NTB;      // blocks whose h is produced and consumed by this wave
+    static_assert(ROLE == 0 ? NTA == NTB : (ROLE == 1 ? NTA + 1 == NTB : NTA == NTB + 1), "role");
+    static_assert(ROLE == 0 || OP, "the mixed tiling exists for the fused out-projection form only");
     constexpr int H = NBH * 16;
     constexpr int ROW1 = H * P::kBytes;             // W1 tile row bytes
     constexpr int XG = ROW1 / 64;                   // K-groups of x
@@ -828,7 +844,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15;
     const int g = lane >> 4;
-    const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
     // gridDim.y > 1: split-hidden mode for token counts that cannot fill the
     // chip -- this workgroup sums only its 1/gridDim.y of the hidden chunks
     // and writes fp32 partial sums; ffn_reduce_ln_kernel finishes the layer.
@@ -892,7 +907,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // B fragments of the wave's tokens: x (bf16 copy / fp32 X), or with OP the
     // attention output, replaced by LN1's result below
     const char* actp = OP ? a.ao : (P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X));
-    u32x4 xf[XG][NT];
+    u32x4 xf[XG][NTX];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int m = tok0 + 16 * t + idx;
@@ -903,6 +918,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             xf[kg][t] = v;
         }
     }
+    // hand-off areas of the mixed tiling: per wave pair (wave & 1), x1 fragments once
+    // (in the second W2 buffer, free until chunk 0 stages W2(1)) and h per chunk
+    // (double buffered, behind the parameter vectors)
+    const uint32_t xfer_x = lds_addr(smem) + 98304 + (wave & 1) * (XG * 1024) + lane * 16;
+    const uint32_t xfer_h = lds_addr(smem) + 131072 + (uint32_t)a.F * 4 + 9 * H * 4 + (wave & 1) * (2 * HG * 1024) + lane * 16;
 
     f32x4 yacc[NBH][NT];
     if constexpr (!OP) {
@@ -915,15 +935,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using LA = FragLayout<ROW1, HB>;
     using LB = FragLayout<ROW2, NBH>;
     constexpr int RA = XG * HB;          // fragments of phase A
-    constexpr int UNITS = HB * NT;       // pack units (one hidden 16-block of one token block)
-    constexpr int DEPTH = NT >= 3 ? 6 : 8;
+    constexpr int UNITS = HB * NTL;      // pack units (one hidden 16-block of one token block)
+    constexpr int DEPTH = NTX >= 3 ? 6 : 8;
     const uint32_t lds0 = lds_addr(smem);
 
     // pack unit u = (hb, t): bias + ReLU on the phase-A accumulator, packed
     // straight into the phase-B B-fragment (see header comment)
-    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NT], u32x4 (&b1f)[HB], u32x4 (&hf)[HG][NT]) {
+    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NTA], u32x4 (&b1f)[HB], u32x4 (&hf)[HG][NTB]) {
         constexpr int u = decltype(uc)::value;
-        constexpr int hb = u / NT, t = u % NT;
+        constexpr int hb = u / NTL, t = u % NTL;
         const u32x4 bv = b1f[hb];
         const float h0 = fmaxf(hsrc[hb][t][0] + __uint_as_float(bv.x), 0.f);
         const float h1 = fmaxf(hsrc[hb][t][1] + __uint_as_float(bv.y), 0.f);
@@ -939,22 +959,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // phase A of chunk c: h^T = W1c x^T (fragment i = (kg, hb)); the VALU of
     // `filler(step)` is issued between the MFMAs so the matrix pipe stays fed
     // (destination: rows OFF .. OFF + HB of `dst`, an [..][NT] accumulator array)
-    auto phase_a_into = [&](int c, auto& dst, auto off_tag, auto filler) {
+    auto phase_a_into = [&](int c, auto& dst, auto off_tag, auto count_tag, auto filler) {
         constexpr int OFF = decltype(off_tag)::value;
+        constexpr int COUNT = decltype(count_tag)::value;       // token blocks
         uint32_t fba[LA::VAR];
         LA::bases(lds0 + (c & 1) * 32768, idx, g, fba);
         lds_stream<LA, RA, DEPTH>(fba, [&](auto ic, const u32x4& wf) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < COUNT; ++t) {
                 if constexpr (i / HB == 0) P::mma0(dst[OFF + i % HB][t], wf, xf[0][t]);
                 else P::mma(dst[OFF + i % HB][t], wf, xf[i / HB][t]);
             }
             filler(ic);
         });
     };
-    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NT], auto filler) {
-        phase_a_into(c, hdst, std::integral_constant<int, 0>{}, filler);
+    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NTA], auto filler) {
+        phase_a_into(c, hdst, std::integral_constant<int, 0>{}, std::integral_constant<int, NTA>{}, filler);
     };
 
 #ifdef PPG_FFN_TIMING
@@ -977,16 +998,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ([&] {
                 dma_wait_barrier();
                 pstamp(1 + 2 * I);
-                phase_a_into(I, yacc, std::integral_constant<int, I * HB>{}, [](auto) {});
+                phase_a_into(I, yacc, std::integral_constant<int, I * HB>{}, std::integral_constant<int, NTB>{}, [](auto) {});
                 __syncthreads();              // buffer I & 1 is free for the tile after next
                 if constexpr (I + 2 < OT) stage_wo(I + 2);
                 else if (I + 2 - OT < NC) stage_w1(I + 2 - OT);
                 pstamp(2 + 2 * I);
             }(), ...);
         }(std::make_integer_sequence<int, OT>{});
-        ln_keep<P, NBH, NT, XG>(yacc, xf, lnp1, a.X, H, tok0, a.M, idx, g);
+        ln_keep<P, NBH, NT, XG, NTX>(yacc, xf, lnp1, a.X, H, tok0, a.M, idx, g);
         pstamp(12);
         // yacc keeps x1: phase B accumulates W2 h on top of the residual
+        if constexpr (ROLE == 1) {
+            // the partner computes the phase A of this wave's last block: hand it the fragments
+#pragma unroll
+            for (int kg = 0; kg < XG; ++kg)
+                asm volatile("ds_write_b128 %0, %1" :: "v"(xfer_x + kg * 1024), "v"(xf[kg][NTB - 1]) : "memory");
+        }
     }
 
     // one chunk: [A(c+1) || pack(c)] -> B(c)
@@ -998,16 +1025,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
     auto stamp = [&](int, int) {};
 #endif
-    auto chunk = [&](int c, f32x4 (&hcur)[HB][NT], f32x4 (&hnext)[HB][NT]) {
+    // ROLE 2: bias + ReLU + pack of the partner's block (index NTA - 1 of this wave's
+    // phase-A set) for hidden chunk c, written to the hand-off buffer c & 1
+    auto pack_foreign = [&](int c, f32x4 (&hsrc)[HB][NTA]) {
+        u32x4 out[HG];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            const float4 bv = *reinterpret_cast<const float4*>(ldsb1 + (size_t)(hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
+            const float v0 = fmaxf(hsrc[hb][NTA - 1][0] + bv.x, 0.f), v1 = fmaxf(hsrc[hb][NTA - 1][1] + bv.y, 0.f);
+            const float v2 = fmaxf(hsrc[hb][NTA - 1][2] + bv.z, 0.f), v3 = fmaxf(hsrc[hb][NTA - 1][3] + bv.w, 0.f);
+            if constexpr (P::kIsBF16) {
+                if (hb & 1) { out[hb >> 1].z = pack_bf16x2(v0, v1); out[hb >> 1].w = pack_bf16x2(v2, v3); }
+                else        { out[hb >> 1].x = pack_bf16x2(v0, v1); out[hb >> 1].y = pack_bf16x2(v2, v3); }
+            } else {
+                out[hb] = u32x4{__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < HG; ++kg)
+            asm volatile("ds_write_b128 %0, %1" :: "v"(xfer_h + ((c & 1) * HG + kg) * 1024), "v"(out[kg]) : "memory");
+    };
+    auto chunk = [&](int c, f32x4 (&hcur)[HB][NTA], f32x4 (&hnext)[HB][NTA]) {
         stamp(c, 0);
         u32x4 b1f[HB];
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
             ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
+        u32x4 hf[HG][NTB];
+        if constexpr (ROLE == 1) {
+            // h of the last block for this chunk: written by the partner before the barrier that ended chunk c - 1
+#pragma unroll
+            for (int kg = 0; kg < HG; ++kg) ds_read_b128_asm<0>(hf[kg][NTB - 1], xfer_h + ((c & 1) * HG + kg) * 1024);
+        }
         if (c + 2 < NC) stage_w1(c + 2);
         if (c + 1 < NC) stage_w2(c + 1);
         stamp(c, 1);
-        u32x4 hf[HG][NT];
         if (c + 1 < NC) {
             phase_a(c + 1, hnext, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -1015,15 +1067,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // stream step 0 waited on an LDS op younger than the b1 reads
 #pragma unroll
                     for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
+                    if constexpr (ROLE == 1) {
+#pragma unroll
+                        for (int kg = 0; kg < HG; ++kg) asm volatile("" : "+v"(hf[kg][NTB - 1]));
+                    }
                 }
                 // spread the UNITS pack units evenly over the RA stream steps
                 if constexpr ((i * UNITS) / RA != ((i + 1) * UNITS) / RA)
                     pack_unit(std::integral_constant<int, (i * UNITS) / RA>{}, hcur, b1f, hf);
             });
+            if constexpr (ROLE == 2) pack_foreign(c + 1, hnext);
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
+            if constexpr (ROLE == 1) {
+#pragma unroll
+                for (int kg = 0; kg < HG; ++kg) asm volatile("" : "+v"(hf[kg][NTB - 1]));
+            }
             [&]<int... U>(std::integer_sequence<int, U...>) {
                 (pack_unit(std::integral_constant<int, U>{}, hcur, b1f, hf), ...);
             }(std::make_integer_sequence<int, UNITS>{});
@@ -1044,18 +1105,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stamp(c, 5);
     };
 
-    f32x4 h0[HB][NT], h1[HB][NT];
+    f32x4 h0[HB][NTA], h1[HB][NTA];
     pstamp(13);
     dma_wait_barrier();
     pstamp(14);
+    if constexpr (ROLE == 2) {
+        // x1 fragments of the partner's block (written before the barrier above)
+#pragma unroll
+        for (int kg = 0; kg < XG; ++kg) ds_read_b128_asm<0>(xf[kg][NTA - 1], xfer_x + kg * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kg = 0; kg < XG; ++kg) asm volatile("" : "+v"(xf[kg][NTA - 1]));
+    }
     phase_a(0, h0, [](auto) {});
-    __syncthreads();                      // W1 buffer 0 is re-filled by chunk 0's DMA
+    if constexpr (ROLE == 2) pack_foreign(0, h0);
+    __syncthreads();                      // W1 buffer 0 is re-filled by chunk 0's DMA; hand-off 0 is written
     for (int c = 0; c < NC; ++c) {
         chunk(c, h0, h1);
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) h0[hb][t] = h1[hb][t];
+            for (int t = 0; t < NTA; ++t) h0[hb][t] = h1[hb][t];
     }
 
     if (a.partial != nullptr) {
@@ -1074,7 +1144,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // (OP: nothing derived from the lane coordinates before the chunk loop may stay live across it)
     int tok0e = tok0, idxe = idx, ge = g;
-    if constexpr (OP) asm volatile("" : "+s"(tok0e), "+v"(idxe), "+v"(ge));
+    if constexpr (OP) {
+        asm volatile("" : "+v"(tok0e), "+v"(idxe), "+v"(ge));
+        tok0e = __builtin_amdgcn_readfirstlane(tok0e);
+    }
     if constexpr (!QKV) {
         resln<P, NBH, NT, OP ? LN_NO_RESIDUAL : LN_EPILOGUE>(yacc, lnp2, a.X, a.Xb, H, tok0e, a.M, idxe, ge);
     } else {
@@ -1215,6 +1288,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             qstamp(i, 5);
         }
     }
+}
+
+template <class P, int NT, int NBH, bool OP, bool QKV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ffn_body<P, NT, NT, NBH, OP, QKV, 0>(a, smem, (blockIdx.x * 4 + wave) * 16 * NT);
+}
+
+// Mixed tiling: 160 tokens per workgroup = waves owning 3, 3, 2, 2 blocks of 16,
+// with the 2-block waves computing the phase A of their partner's third block
+// (ffn_body ROLE 1 / 2): every wave runs 5 block-phases per chunk instead of 6.
+// At the benchmark shape (40 960 token rows on 256 CUs = 160 rows per CU) this is
+// one workgroup on every CU where 192-token workgroups leave 42 CUs idle.
+template <class P, int NBH, bool QKV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_mixed_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int base = blockIdx.x * 160;
+    if (wave < 2) ffn_body<P, 2, 3, NBH, true, QKV, 1>(a, smem, base + wave * 48);
+    else ffn_body<P, 3, 2, NBH, true, QKV, 2>(a, smem, base + 96 + (wave - 2) * 32);
 }
 
 // Second half of the split-hidden FFN: X <- LN(X + b2 + sum_s partial[s]).
@@ -1555,6 +1649,26 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <class P, bool QKV>
+hipError_t launch_ffn_mixed(const FfnArgs& a, hipStream_t s) {
+    if constexpr (!P::kIsBF16) {
+        return hipErrorInvalidValue;
+    } else {
+        if (a.H != 256 || a.partial != nullptr) return hipErrorInvalidValue;
+        auto kern = ffn_mixed_kernel<P, 16, QKV>;
+        constexpr int HG = 2;                                  // K-groups of a 64-hidden chunk in bf16
+        const size_t lds = 131072 + (size_t)a.F * 4 + 9 * (size_t)a.H * 4 + 2 * 2 * HG * 1024;
+        static size_t configured = 0;
+        if (configured < lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3((a.M + 159) / 160), dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
+}
+
 template <class P, bool OP, bool QKV>
 hipError_t launch_ffn_op(const FfnArgs& a, int nt, hipStream_t s) {
     if (a.H == 256) {
@@ -1570,6 +1684,7 @@ template <class P>
 hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
     if (a.Wo != nullptr) {
         if (a.partial != nullptr) return hipErrorInvalidValue;   // every split would redo the out-projection
+        if (nt == ppg::kFfnMixedTiling) return a.Wq != nullptr ? launch_ffn_mixed<P, true>(a, s) : launch_ffn_mixed<P, false>(a, s);
         if (a.Wq != nullptr) return launch_ffn_op<P, true, true>(a, nt, s);
         return launch_ffn_op<P, true, false>(a, nt, s);
     }

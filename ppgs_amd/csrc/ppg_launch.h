@@ -14,6 +14,9 @@ hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 
 hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s);
+// nt: 16-token blocks per wave (1..3), or kFfnMixedTiling = 160-token workgroups with waves of 3, 3, 2, 2
+// blocks that balance their work through LDS (bf16, hidden 256, fused out-projection only)
+constexpr int kFfnMixedTiling = 5;
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
 
