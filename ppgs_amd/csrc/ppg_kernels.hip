@@ -898,10 +898,10 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         reinterpret_cast<float4*>(ldsb1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
     // LayerNorm parameters behind b1: [b2 | gamma2 | beta2] and, with OP, [bo | gamma1 | beta1]
     float* lnp2 = reinterpret_cast<float*>(ldsb1) + a.F;
-    float* lnp1 = lnp2 + 3 * H;
+    float* ldsbq = lnp2 + 3 * H;          // QKV: the next layer's in_proj bias, 3H floats
+    float* lnp1 = ldsbq + 3 * H;          // last: dead after LN1, the mixed tiling's h hand-off overlays it
     stage_params(lnp2, H, tid, a.b2, a.gamma, a.beta);
     if constexpr (OP) stage_params(lnp1, H, tid, a.bo, a.g1, a.e1);
-    float* ldsbq = lnp1 + 3 * H;          // QKV: the next layer's in_proj bias, 3H floats
     if constexpr (QKV) stage_params(ldsbq, H, tid, a.bq, a.bq + H, a.bq + 2 * H);
 
     // B fragments of the wave's tokens: x (bf16 copy / fp32 X), or with OP the
@@ -919,10 +919,11 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         }
     }
     // hand-off areas of the mixed tiling: per wave pair (wave & 1), x1 fragments once
-    // (in the second W2 buffer, free until chunk 0 stages W2(1)) and h per chunk
-    // (double buffered, behind the parameter vectors)
+    // (in the second W2 buffer, free until chunk 0 stages W2(1)) and the raw fp32 h
+    // accumulators of one block per chunk (double buffered; from the LN1 parameters on,
+    // which are dead by then)
     const uint32_t xfer_x = lds_addr(smem) + 98304 + (wave & 1) * (XG * 1024) + lane * 16;
-    const uint32_t xfer_h = lds_addr(smem) + 131072 + (uint32_t)a.F * 4 + 9 * H * 4 + (wave & 1) * (2 * HG * 1024) + lane * 16;
+    const uint32_t xfer_h = lds_addr(smem) + 131072 + (uint32_t)a.F * 4 + 6 * H * 4 + (wave & 1) * (2 * HB * 1024) + lane * 16;
 
     f32x4 yacc[NBH][NT];
     if constexpr (!OP) {
@@ -935,20 +936,22 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
     using LA = FragLayout<ROW1, HB>;
     using LB = FragLayout<ROW2, NBH>;
     constexpr int RA = XG * HB;          // fragments of phase A
-    constexpr int UNITS = HB * NTL;      // pack units (one hidden 16-block of one token block)
+    constexpr int UNITS = HB * NTB;      // pack units (one hidden 16-block of one token block the wave owns)
     constexpr int DEPTH = NTX >= 3 ? 6 : 8;
     const uint32_t lds0 = lds_addr(smem);
 
     // pack unit u = (hb, t): bias + ReLU on the phase-A accumulator, packed
     // straight into the phase-B B-fragment (see header comment)
-    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NTA], u32x4 (&b1f)[HB], u32x4 (&hf)[HG][NTB]) {
+    // (ROLE 1: the last owned block's accumulators come from the partner wave: hfar)
+    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NTA], f32x4 (&hfar)[HB], u32x4 (&b1f)[HB], u32x4 (&hf)[HG][NTB]) {
         constexpr int u = decltype(uc)::value;
-        constexpr int hb = u / NTL, t = u % NTL;
+        constexpr int hb = u / NTB, t = u % NTB;
         const u32x4 bv = b1f[hb];
-        const float h0 = fmaxf(hsrc[hb][t][0] + __uint_as_float(bv.x), 0.f);
-        const float h1 = fmaxf(hsrc[hb][t][1] + __uint_as_float(bv.y), 0.f);
-        const float h2 = fmaxf(hsrc[hb][t][2] + __uint_as_float(bv.z), 0.f);
-        const float h3 = fmaxf(hsrc[hb][t][3] + __uint_as_float(bv.w), 0.f);
+        const f32x4 hv = [&] { if constexpr (t < NTL) return hsrc[hb][t]; else return hfar[hb]; }();
+        const float h0 = fmaxf(hv[0] + __uint_as_float(bv.x), 0.f);
+        const float h1 = fmaxf(hv[1] + __uint_as_float(bv.y), 0.f);
+        const float h2 = fmaxf(hv[2] + __uint_as_float(bv.z), 0.f);
+        const float h3 = fmaxf(hv[3] + __uint_as_float(bv.w), 0.f);
         if constexpr (P::kIsBF16) {
             if constexpr (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
             else                  { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
@@ -1025,25 +1028,13 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
 #else
     auto stamp = [&](int, int) {};
 #endif
-    // ROLE 2: bias + ReLU + pack of the partner's block (index NTA - 1 of this wave's
-    // phase-A set) for hidden chunk c, written to the hand-off buffer c & 1
-    auto pack_foreign = [&](int c, f32x4 (&hsrc)[HB][NTA]) {
-        u32x4 out[HG];
+    // ROLE 2: the raw phase-A accumulators of the partner's block (index NTA - 1 of
+    // this wave's phase-A set) for hidden chunk c go to hand-off buffer c & 1; the
+    // owner applies bias, ReLU and packing among its own pack units
+    auto send_foreign = [&](int c, f32x4 (&hsrc)[HB][NTA]) {
 #pragma unroll
-        for (int hb = 0; hb < HB; ++hb) {
-            const float4 bv = *reinterpret_cast<const float4*>(ldsb1 + (size_t)(hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
-            const float v0 = fmaxf(hsrc[hb][NTA - 1][0] + bv.x, 0.f), v1 = fmaxf(hsrc[hb][NTA - 1][1] + bv.y, 0.f);
-            const float v2 = fmaxf(hsrc[hb][NTA - 1][2] + bv.z, 0.f), v3 = fmaxf(hsrc[hb][NTA - 1][3] + bv.w, 0.f);
-            if constexpr (P::kIsBF16) {
-                if (hb & 1) { out[hb >> 1].z = pack_bf16x2(v0, v1); out[hb >> 1].w = pack_bf16x2(v2, v3); }
-                else        { out[hb >> 1].x = pack_bf16x2(v0, v1); out[hb >> 1].y = pack_bf16x2(v2, v3); }
-            } else {
-                out[hb] = u32x4{__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
-            }
-        }
-#pragma unroll
-        for (int kg = 0; kg < HG; ++kg)
-            asm volatile("ds_write_b128 %0, %1" :: "v"(xfer_h + ((c & 1) * HG + kg) * 1024), "v"(out[kg]) : "memory");
+        for (int hb = 0; hb < HB; ++hb)
+            asm volatile("ds_write_b128 %0, %1" :: "v"(xfer_h + ((c & 1) * HB + hb) * 1024), "v"(hsrc[hb][NTA - 1]) : "memory");
     };
     auto chunk = [&](int c, f32x4 (&hcur)[HB][NTA], f32x4 (&hnext)[HB][NTA]) {
         stamp(c, 0);
@@ -1052,10 +1043,15 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         for (int hb = 0; hb < HB; ++hb)
             ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
         u32x4 hf[HG][NTB];
+        f32x4 hfar[HB];
         if constexpr (ROLE == 1) {
-            // h of the last block for this chunk: written by the partner before the barrier that ended chunk c - 1
+            // raw h of the last block for this chunk: written by the partner before the barrier that ended chunk c - 1
 #pragma unroll
-            for (int kg = 0; kg < HG; ++kg) ds_read_b128_asm<0>(hf[kg][NTB - 1], xfer_h + ((c & 1) * HG + kg) * 1024);
+            for (int hb = 0; hb < HB; ++hb) {
+                u32x4 raw;
+                ds_read_b128_asm<0>(raw, xfer_h + ((c & 1) * HB + hb) * 1024);
+                hfar[hb] = __builtin_bit_cast(f32x4, raw);
+            }
         }
         if (c + 2 < NC) stage_w1(c + 2);
         if (c + 1 < NC) stage_w2(c + 1);
@@ -1069,24 +1065,24 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
                     for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
                     if constexpr (ROLE == 1) {
 #pragma unroll
-                        for (int kg = 0; kg < HG; ++kg) asm volatile("" : "+v"(hf[kg][NTB - 1]));
+                        for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(hfar[hb]));
                     }
                 }
                 // spread the UNITS pack units evenly over the RA stream steps
                 if constexpr ((i * UNITS) / RA != ((i + 1) * UNITS) / RA)
-                    pack_unit(std::integral_constant<int, (i * UNITS) / RA>{}, hcur, b1f, hf);
+                    pack_unit(std::integral_constant<int, (i * UNITS) / RA>{}, hcur, hfar, b1f, hf);
             });
-            if constexpr (ROLE == 2) pack_foreign(c + 1, hnext);
+            if constexpr (ROLE == 2) send_foreign(c + 1, hnext);
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
             if constexpr (ROLE == 1) {
 #pragma unroll
-                for (int kg = 0; kg < HG; ++kg) asm volatile("" : "+v"(hf[kg][NTB - 1]));
+                for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(hfar[hb]));
             }
             [&]<int... U>(std::integer_sequence<int, U...>) {
-                (pack_unit(std::integral_constant<int, U>{}, hcur, b1f, hf), ...);
+                (pack_unit(std::integral_constant<int, U>{}, hcur, hfar, b1f, hf), ...);
             }(std::make_integer_sequence<int, UNITS>{});
         }
         stamp(c, 2);
@@ -1118,7 +1114,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         for (int kg = 0; kg < XG; ++kg) asm volatile("" : "+v"(xf[kg][NTA - 1]));
     }
     phase_a(0, h0, [](auto) {});
-    if constexpr (ROLE == 2) pack_foreign(0, h0);
+    if constexpr (ROLE == 2) send_foreign(0, h0);
     __syncthreads();                      // W1 buffer 0 is re-filled by chunk 0's DMA; hand-off 0 is written
     for (int c = 0; c < NC; ++c) {
         chunk(c, h0, h1);
@@ -1635,7 +1631,7 @@ template <class P, int NT, int NBH, bool OP, bool QKV>
 hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const dim3 blocks((a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
     auto kern = ffn_kernel<P, NT, NBH, OP, QKV>;
-    const size_t lds = 131072 + (size_t)a.F * 4 + (QKV ? 9 : 6) * (size_t)a.H * 4;
+    const size_t lds = 131072 + (size_t)a.F * 4 + ((OP || QKV) ? 9 : 6) * (size_t)a.H * 4;   // b1, [b2 g2 e2], [bq], [bo g1 e1]
     static size_t configured = 0;            // once per process and size: not a stream operation
     if (configured < lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1656,8 +1652,9 @@ hipError_t launch_ffn_mixed(const FfnArgs& a, hipStream_t s) {
     } else {
         if (a.H != 256 || a.partial != nullptr) return hipErrorInvalidValue;
         auto kern = ffn_mixed_kernel<P, 16, QKV>;
-        constexpr int HG = 2;                                  // K-groups of a 64-hidden chunk in bf16
-        const size_t lds = 131072 + (size_t)a.F * 4 + 9 * (size_t)a.H * 4 + 2 * 2 * HG * 1024;
+        constexpr int HB = 4;                                  // 16-row blocks of a 64-hidden chunk (hidden 256, bf16)
+        // hand-off: 2 wave pairs x 2 buffers x HB KiB of raw accumulators, from the LN1 parameters on
+        const size_t lds = 131072 + (size_t)a.F * 4 + 6 * (size_t)a.H * 4 + 2 * 2 * HB * 1024;
         static size_t configured = 0;
         if (configured < lds) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
