@@ -92,7 +92,7 @@ def cpu_baseline(state, seconds):
     }
 
 
-def pmc_traffic(kernel='ffn_kernel'):
+def pmc_traffic(kernel='ffn_'):
     """HBM-side bytes per launch of the dominant kernel from the newest
     committed rocprofv3 PMC summary (profiles/r*_pmc_summary.txt; separate
     --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 reports half of
@@ -106,7 +106,7 @@ def pmc_traffic(kernel='ffn_kernel'):
     lines = [line for line in open(files[-1]) if line.startswith(kernel)]
     # several variants of the kernel in one run: the one with the Q/K/V tail
     # (4 of the 5 launches of a step) is the one the roofline line describes
-    tail = [line for line in lines if 'true, true>' in line]
+    tail = [line for line in lines if 'true>' in line.split(':')[0]]
     for line in tail or lines:
         if line.startswith(kernel):
             m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
@@ -224,7 +224,7 @@ def main():
                 'parallelism': f'utterance-sharded x{world}, no data-path collective',
             },
             'roofline': {
-                'kernel': ('ffn_kernel (fused out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
+                'kernel': ('ffn_mixed_kernel (the layer kernel at this shape: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
                            + (', next layer Q/K/V)' if qkv_fused_layers else ')') if op_fused
                            else 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)'),
                 'bound': 'mfma',
