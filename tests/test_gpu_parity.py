@@ -234,15 +234,23 @@ def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
     monkeypatch.setenv('PPGS_AMD_QKV_FUSED', '0')
     no_tail = E.Engine(state, 0, precision)
     monkeypatch.delenv('PPGS_AMD_QKV_FUSED')
+    # bf16, hidden 256: the default tiling here is the mixed one (160-token workgroups,
+    # waves of 3/3/2/2 blocks trading one block's phase A through LDS); also run the
+    # plain 48-tokens-per-wave tiling of the same kernel
+    monkeypatch.setenv('PPGS_AMD_FFN_MIXED', '0')
+    plain = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_FFN_MIXED')
     ref = O.from_features(state, feats, torch.tensor(lengths)).numpy()
     out_pieces = run(pieces, feats, lengths)
     out_no_tail = run(no_tail, feats, lengths)
+    out_plain = run(plain, feats, lengths)
     # tolerances: fp32 = the parity bar; bf16 = what test_bf16_mode allows
     tol = FP32_TOL if precision == 'fp32' else BF16_TOL
     same = 2e-5 if precision == 'fp32' else 1e-2      # bf16: x1 is rounded at a different point when kept in registers
     assert np.abs(out - ref).max() < tol
     assert np.abs(out - out_pieces).max() < same
     assert np.abs(out - out_no_tail).max() < same
+    assert np.abs(out - out_plain).max() < 2e-5 + (0 if precision == 'fp32' else 2e-3)   # same arithmetic, other summation order
     for b, n in enumerate(lengths):
         assert np.allclose(out[b, :, n:], 1 / 40)
 
