@@ -50,16 +50,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 }
 
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): the LDS address is the
-// wave-uniform base + lane*16, the global address is per lane.
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)gsrc,
-        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-// The same DMA in its scalar-base form: wave-uniform 64-bit base in SGPRs + a
-// 32-bit per-lane offset that is never rewritten.  hipcc expands the builtin
-// to a 64-bit VALU add into one VGPR pair per piece, reused by the next piece,
-// so every piece waits for the previous one to have read its address.
+// wave-uniform base (M0) + lane*16, the global address is per lane.  Issued from
+// inline asm in the scalar-base form -- wave-uniform 64-bit base in SGPRs + a
+// 32-bit per-lane offset that is never rewritten: hipcc expands the
+// __builtin_amdgcn_global_load_lds builtin to a 64-bit VALU add into one VGPR
+// pair per piece, reused by the next piece, so every piece waits for the
+// previous one to have read its address (-4 % layer kernel, -8 % attention).
 __device__ __forceinline__ void glds16_saddr(const char* uniform_base, uint32_t lane_off, uint32_t lds_wave_addr) {
     // (readfirstlane: free where the compiler already knows the value is wave-uniform, and the
     // only way to get SGPR operands where it does not -- both bodies of ffn_mixed_kernel)
