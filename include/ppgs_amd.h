@@ -194,6 +194,18 @@ int ppg_frontend(int device, const float* audio, int batch, int samples,
                  void* spec, void* mel, void* stream);
 
 /*
+ * Sample-rate conversion on the device: replaces ppgs.resample
+ * (ppgs/core.py:599-608 = torchaudio.transforms.Resample with its defaults:
+ * Hann-windowed sinc, lowpass_filter_width 6, rolloff 0.99), which the
+ * reference applies to loaded audio that is not at 16 kHz (ppgs/load.py:29-30).
+ *   audio: device fp32 (batch, samples) at orig_rate
+ *   out  : device fp32 (batch, ppg_resample_length(samples, orig_rate, new_rate))
+ */
+int64_t ppg_resample_length(int64_t samples, int orig_rate, int new_rate);
+int ppg_resample(int device, const float* audio, int batch, int64_t samples,
+                 int orig_rate, int new_rate, float* out, void* stream);
+
+/*
  * Per-kernel-class timing with HIP events on the launch stream (used by
  * bench.py's roofline leg).  `classes` is a bitmask of (1 << PPG_K_*), 0 =
  * off, -1 = every class (each timed launch costs two event records on the

@@ -305,3 +305,36 @@ def sampler_batches(lengths, max_frames, seed=1234, epoch=0, buckets=1):
             batches.append(batch)
     order = torch.randperm(len(batches), generator=generator).tolist()
     return [batches[i] for i in order]
+
+
+def resample(audio, sample_rate, target_rate=16000):
+    """torchaudio.transforms.Resample with its defaults (sinc_interp_hann,
+    lowpass_filter_width 6, rolloff 0.99), which reference ppgs/core.py:599-608
+    applies to audio that is not at 16 kHz.  torchaudio is absent here: this is
+    its published algorithm restated (functional.py: _get_sinc_resample_kernel +
+    _apply_sinc_resample_kernel), i.e. parity-unpinned against the real package."""
+    if sample_rate == target_rate:
+        return audio
+    orig, new = int(sample_rate), int(target_rate)
+    gcd = math.gcd(orig, new)
+    orig, new = orig // gcd, new // gcd
+    lowpass_filter_width, rolloff = 6, 0.99
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
+    kernels = (kernels * window * scale).to(torch.float32)
+    shape = audio.shape
+    flat = audio.reshape(-1, shape[-1]).to(torch.float32)
+    length = flat.shape[-1]
+    padded = torch.nn.functional.pad(flat, (width, width + orig))
+    out = torch.nn.functional.conv1d(padded[:, None], kernels, stride=orig)
+    out = out.transpose(1, 2).reshape(flat.shape[0], -1)
+    target_length = math.ceil(new * length / orig)
+    return out[..., :target_length].reshape(shape[:-1] + (target_length,))
+

@@ -321,6 +321,9 @@ def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
     """
     if sample_rate == target_rate:
         return audio
+    if audio.is_cuda:                       # device tensors: the HIP kernel (ppg_resample)
+        return engine.resample(audio, sample_rate, target_rate)
+    # host tensors (file loading before the H2D copy): the same filter in torch
     orig, new = int(sample_rate), int(target_rate)
     gcd = math.gcd(orig, new)
     orig, new = orig // gcd, new // gcd

@@ -610,6 +610,18 @@ int frontend_for(int device, Frontend** out) {
 
 }  // namespace
 
+namespace ppg {
+// error reporting for the other translation units of the library (ppg_resample.hip)
+int fail_message(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return fail(code, "%s", buf);
+}
+}  // namespace ppg
+
 // ============================================================================
 // C ABI
 // ============================================================================

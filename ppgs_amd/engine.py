@@ -83,6 +83,11 @@ SYMBOLS = {
     'ppg_frontend': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_resample_length': (ctypes.c_int64, [
+        ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'ppg_resample': (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'ppg_engine_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'ppg_engine_profile_read': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
@@ -362,6 +367,24 @@ def frontend(audio, spectrogram=False, mel=True):
             spec_out.data_ptr() if spectrogram else None,
             mel_out.data_ptr() if mel else None, stream))
     return spec_out, mel_out
+
+
+def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
+    """(..., samples) fp32 on a GPU at sample_rate -> (..., samples') at
+    target_rate, torchaudio.transforms.Resample defaults (ppg_resample)."""
+    if not audio.is_cuda:
+        raise PpgError('ppgs_amd: the native resampler works on a HIP device tensor')
+    shape = audio.shape
+    flat = audio.reshape(-1, shape[-1]).to(torch.float32).contiguous()
+    lib = library()
+    length = lib.ppg_resample_length(flat.shape[1], int(sample_rate), int(target_rate))
+    out = torch.empty((flat.shape[0], length), dtype=torch.float32, device=audio.device)
+    with torch.cuda.device(audio.device):
+        _check(lib.ppg_resample(
+            audio.device.index, flat.data_ptr(), flat.shape[0], flat.shape[1],
+            int(sample_rate), int(target_rate), out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream))
+    return out.reshape(shape[:-1] + (length,))
 
 
 def frontend_profile(device, enable=True):

@@ -92,6 +92,26 @@ def test_frontend_odd_frames_vs_oracle():
     assert d.max() <= 1 and (d == 0).mean() >= 0.995
 
 
+@pytest.mark.parametrize('rate', [48000, 44100, 22050, 8000, 16001])
+def test_resample_matches_oracle(rate):
+    """ppg_resample (device) against the oracle's restatement of torchaudio's
+    windowed-sinc resampler; fp32 dot products of <= ~500 taps in a different
+    order, hence 2e-6 absolute on 0.1-scale audio."""
+    gen = torch.Generator().manual_seed(rate)
+    audio = 0.1 * torch.randn(3, 1, rate // 3 + 17, generator=gen)
+    ref = O.resample(audio, rate)
+    out = ppgs_amd.resample(audio.cuda(), rate)
+    assert out.is_cuda and out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max() < 2e-6
+    # the host branch of the API (file loading) is the same filter
+    assert (ppgs_amd.resample(audio, rate) - ref).abs().max() < 1e-6
+    # through the API's preprocessing: 48 kHz audio -> 16 kHz mel frames
+    if rate == 48000:
+        mel = ppgs_amd.preprocess.from_audio(audio[:1].cuda(), sample_rate=rate, gpu=0)
+        assert mel.shape == (1, 80, ref.shape[-1] // 160)
+        assert ulp_diff(mel.cpu().numpy(), O.mel_from_audios(ref[:1]).numpy()).max() <= 1
+
+
 # ------------------------------------------------------------------- model --
 
 @pytest.mark.parametrize('layers', [0, 1])
