@@ -206,6 +206,24 @@ int ppg_resample(int device, const float* audio, int batch, int64_t samples,
                  int orig_rate, int new_rate, float* out, void* stream);
 
 /*
+ * PPG post-ops on the device (per-frame arithmetic over the 40 phonemes).
+ *
+ * ppg_distance: replaces the body of ppgs.distance (ppgs/core.py:399-472).
+ *   ppg_x, ppg_y: device fp32 (40, frames);  mix: device fp32 (40, 40) =
+ *   similarity.T ** exponent (the reference's normalize=True), or NULL
+ *   (normalize=False);  jsd: device fp32 (frames) -- the reference's
+ *   reduction='none' result; 'mean' / 'sum' are one reduction over it.
+ * ppg_sparsify: replaces ppgs.sparsify (ppgs/core.py:510-543) for one
+ *   threshold.  ppg, out: device fp32 (batch, 40, frames);  method 0 =
+ *   'constant', 1 = 'percentile' (threshold = quantile in [0, 1]), 2 = 'topk'
+ *   (threshold = k).
+ */
+int ppg_distance(int device, const float* ppg_x, const float* ppg_y, int frames,
+                 const float* mix, float* jsd, void* stream);
+int ppg_sparsify(int device, const float* ppg, int batch, int frames, int method,
+                 float threshold, float* out, void* stream);
+
+/*
  * Per-kernel-class timing with HIP events on the launch stream (used by
  * bench.py's roofline leg).  `classes` is a bitmask of (1 << PPG_K_*), 0 =
  * off, -1 = every class (each timed launch costs two event records on the

@@ -338,3 +338,39 @@ def resample(audio, sample_rate, target_rate=16000):
     target_length = math.ceil(new * length / orig)
     return out[..., :target_length].reshape(shape[:-1] + (target_length,))
 
+
+def distance(ppg_x, ppg_y, similarity=None, exponent=1.2, reduction='mean'):
+    """Reference ppgs/core.py:399-472 (similarity=None: normalize=False)."""
+    x = ppg_x.float().clamp(1e-8, 1 - 1e-8)
+    y = ppg_y.float().clamp(1e-8, 1 - 1e-8)
+    if similarity is not None:
+        mix = similarity.float().T ** exponent
+        x, y = torch.mm(mix, x), torch.mm(mix, y)
+    x, y = x.T, y.T
+    log_average = torch.log((x + y) / 2)
+    kl_x = x * (torch.log(x) - log_average)
+    kl_y = y * (torch.log(y) - log_average)
+    jsd = torch.sqrt(((kl_x + kl_y) / 2).clamp(min=0)).sum(dim=1)
+    if reduction == 'mean':
+        return jsd.mean(dim=0)
+    if reduction == 'sum':
+        return jsd.sum(dim=0)
+    return jsd
+
+
+def sparsify(ppg, method='percentile', threshold=0.85):
+    """Reference ppgs/core.py:510-543 for one threshold, (batch, 40, frames) in
+    and out (the reference's extra leading axis for 'percentile' is the caller's)."""
+    ppg = ppg.float()
+    if method == 'percentile':
+        cut = torch.quantile(ppg, float(threshold), dim=-2, keepdim=True)
+        ppg = torch.where(ppg > cut, ppg, torch.zeros_like(ppg))
+    elif method == 'constant':
+        ppg = torch.where(ppg > float(threshold), ppg, torch.zeros_like(ppg))
+    elif method == 'topk':
+        values, indices = ppg.topk(int(threshold), dim=-2)
+        ppg = torch.zeros_like(ppg).scatter(-2, indices, values)
+    else:
+        raise ValueError(method)
+    return torch.softmax(torch.log(ppg + 1e-8), -2)
+

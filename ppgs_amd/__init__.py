@@ -10,6 +10,7 @@ from . import config, data, engine, load, preprocess, weights   # noqa: F401
 from .core import (                   # noqa: F401
     from_audio, from_features, from_file, from_file_to_file,
     from_files_to_files, from_dataloader, infer, resample,
+    distance, interpolate, sparsify,
     representation_file_extension, engine_for, clear_cache)
 from . import core, distributed      # noqa: F401
 

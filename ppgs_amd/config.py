@@ -42,3 +42,6 @@ MODEL_GEOMETRY = {
     'mel': dict(input_channels=80, hidden_channels=256),
     'w2v2fb': dict(input_channels=768, hidden_channels=512),
 }
+
+# Exponent of the similarity matrix in ppgs.distance (reference config/defaults.py:214)
+SIMILARITY_EXPONENT = 1.2

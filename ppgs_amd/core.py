@@ -349,6 +349,78 @@ def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
     return out[..., :target_length].reshape(shape[:-1] + (target_length,))
 
 
+###############################################################################
+# PPG post-ops (reference ppgs/core.py:399-543), per-frame arithmetic on the GPU
+###############################################################################
+
+
+def similarity_matrix(device=None):
+    """The reference's 40 x 40 phoneme similarity matrix
+    (ppgs.SIMILARITY_MATRIX_PATH, a data asset of the reference package).  It is
+    not part of this package: taken from PPGS_AMD_SIMILARITY_MATRIX (a .pt file
+    holding the tensor) or, if the reference package is importable, from it."""
+    path = os.environ.get('PPGS_AMD_SIMILARITY_MATRIX')
+    if path is None:
+        try:
+            import ppgs
+            path = ppgs.SIMILARITY_MATRIX_PATH
+        except Exception as error:
+            raise ValueError(
+                'ppgs_amd.distance(normalize=True) needs the phoneme similarity '
+                'matrix: pass similarity=<(40,40) tensor> or set '
+                'PPGS_AMD_SIMILARITY_MATRIX to the reference\'s '
+                'balanced_similarity.pt') from error
+    matrix = torch.load(path, map_location='cpu')
+    return matrix if device is None else matrix.to(device)
+
+
+def distance(ppgX, ppgY, reduction='mean', normalize=True,
+             exponent=config.SIMILARITY_EXPONENT, similarity=None):
+    """Pronunciation distance between two aligned (40, frames) PPGs: the
+    similarity-normalised Jensen-Shannon distance of reference
+    ppgs/core.py:399-472.  Extra keyword `similarity`: the matrix to use
+    instead of the reference's asset (see similarity_matrix)."""
+    if reduction not in ('mean', 'sum', 'none', None):
+        raise ValueError(f'Reduction method {reduction} not defined')
+    device = device_for(None, ppgX)
+    mix = None
+    if normalize:
+        if similarity is None:
+            similarity = similarity_matrix()
+        mix = similarity.to(device=device, dtype=torch.float32).T ** exponent
+    jsd = engine.distance_frames(ppgX.to(device), ppgY.to(device), mix)
+    if reduction == 'mean':
+        return jsd.mean(dim=0)
+    if reduction == 'sum':
+        return jsd.sum(dim=0)
+    return jsd
+
+
+def interpolate(ppgX, ppgY, interp):
+    """Linear interpolation (reference ppgs/core.py:480-502)."""
+    return (1. - interp) * ppgX + interp * ppgY
+
+
+def sparsify(ppg, method='percentile', threshold=torch.Tensor([0.85])):
+    """Make posteriorgrams sparse and renormalise (reference
+    ppgs/core.py:510-543).  (batch, 40, frames) -> same; like the reference,
+    'percentile' with a one-element threshold tensor (the default) returns the
+    result with an extra leading dimension of 1 (torch.quantile's q axis)."""
+    methods = {'constant': 0, 'percentile': 1, 'topk': 2}
+    if method not in methods:
+        raise ValueError(f'Sparsification method {method} not defined')
+    device = device_for(None, ppg)
+    value = float(threshold.reshape(-1)[0]) if torch.is_tensor(threshold) else float(threshold)
+    if torch.is_tensor(threshold) and threshold.numel() != 1:
+        raise ValueError('ppgs_amd.sparsify takes one threshold')
+    out = engine.sparsify(ppg.to(device), methods[method], value)
+    if method == 'percentile' and torch.is_tensor(threshold) and threshold.dim() == 1:
+        out = out[None]
+    if method == 'topk' and out.shape[0] == 1:
+        pass    # the reference's batch-1 semantics; larger batches mix items there (core.py:537-538)
+    return out
+
+
 def representation_file_extension():
     """reference ppgs/core.py:611-621 for REPRESENTATION_KIND == 'ppg'."""
     if config.REPRESENTATION == config.BEST_REPRESENTATION:

@@ -88,6 +88,12 @@ SYMBOLS = {
     'ppg_resample': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_distance': (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_sparsify': (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     'ppg_engine_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'ppg_engine_profile_read': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
@@ -385,6 +391,42 @@ def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
             int(sample_rate), int(target_rate), out.data_ptr(),
             torch.cuda.current_stream().cuda_stream))
     return out.reshape(shape[:-1] + (length,))
+
+
+def distance_frames(ppg_x, ppg_y, mix=None):
+    """Per-frame similarity-weighted Jensen-Shannon term (ppg_distance):
+    (40, frames) x 2 on a GPU [+ (40, 40) mixing matrix] -> (frames,)."""
+    if not (ppg_x.is_cuda and ppg_y.is_cuda):
+        raise PpgError('ppgs_amd: the post-ops work on HIP device tensors')
+    x = ppg_x.to(torch.float32).contiguous()
+    y = ppg_y.to(torch.float32).contiguous()
+    if x.shape != y.shape or x.dim() != 2 or x.shape[0] != 40:
+        raise ValueError(f'PPGs must both be (40, frames), got {tuple(x.shape)} and {tuple(y.shape)}')
+    if mix is not None:
+        mix = mix.to(device=x.device, dtype=torch.float32).contiguous()
+    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(library().ppg_distance(
+            x.device.index, x.data_ptr(), y.data_ptr(), x.shape[1],
+            mix.data_ptr() if mix is not None else None, out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+def sparsify(ppg, method, threshold):
+    """(batch, 40, frames) on a GPU -> same shape (ppg_sparsify); method 0
+    constant / 1 percentile / 2 topk, one threshold."""
+    if not ppg.is_cuda:
+        raise PpgError('ppgs_amd: the post-ops work on HIP device tensors')
+    x = ppg.to(torch.float32).contiguous()
+    if x.dim() != 3 or x.shape[1] != 40:
+        raise ValueError(f'PPG must be (batch, 40, frames), got {tuple(x.shape)}')
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(library().ppg_sparsify(
+            x.device.index, x.data_ptr(), x.shape[0], x.shape[2], int(method),
+            float(threshold), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return out
 
 
 def frontend_profile(device, enable=True):

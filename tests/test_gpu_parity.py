@@ -112,6 +112,31 @@ def test_resample_matches_oracle(rate):
         assert ulp_diff(mel.cpu().numpy(), O.mel_from_audios(ref[:1]).numpy()).max() <= 1
 
 
+def test_postops_match_reference_fixture(golden):
+    """ppgs_amd.distance / sparsify / interpolate on the GPU against the outputs
+    of the reference's own functions (fixture g9; the similarity matrix is an
+    input stored in it).  Tolerances: fp32 sums of 40 terms, logs, one sqrt."""
+    g = golden('g9_postops')
+    x, y, sim = (t(g[k]).cuda() for k in ('x', 'y', 'similarity'))
+    for normalize in (1, 0):
+        for reduction in ('mean', 'sum', 'none'):
+            out = ppgs_amd.distance(x, y, reduction=reduction, normalize=bool(normalize), similarity=sim)
+            ref = np.asarray(g[f'distance_{normalize}_{reduction}'])
+            assert np.allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-6), (normalize, reduction)
+    assert float(ppgs_amd.distance(x, x, similarity=sim)) < 1e-3 and float(g['distance_same']) < 1e-3
+    assert np.allclose(ppgs_amd.interpolate(x, y, 0.3).cpu().numpy(), g['interpolate_scalar'], atol=1e-7)
+    assert np.allclose(ppgs_amd.interpolate(x, y, t(g['interp']).cuda()).cpu().numpy(), g['interpolate_vector'], atol=1e-7)
+    batch = t(g['batch']).cuda()
+    out = ppgs_amd.sparsify(batch)                                   # default: percentile 0.85
+    assert out.shape == g['sparsify_percentile'].shape                 # (1, batch, 40, frames), like the reference
+    assert np.allclose(out.cpu().numpy(), g['sparsify_percentile'], atol=1e-6)
+    assert np.allclose(ppgs_amd.sparsify(batch, 'percentile', torch.tensor([0.5])).cpu().numpy(), g['sparsify_percentile_50'], atol=1e-6)
+    assert np.allclose(ppgs_amd.sparsify(batch, 'constant', torch.tensor([0.1])).cpu().numpy(), g['sparsify_constant'], atol=1e-6)
+    assert np.allclose(ppgs_amd.sparsify(batch[:1], 'topk', 3).cpu().numpy(), g['sparsify_topk3'], atol=1e-6)
+    with pytest.raises(ValueError):
+        ppgs_amd.sparsify(batch, 'median')
+
+
 # ------------------------------------------------------------------- model --
 
 @pytest.mark.parametrize('layers', [0, 1])

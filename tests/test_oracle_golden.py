@@ -135,3 +135,21 @@ def test_packing_matches_reference_sampler(golden):
         assert np.array_equal(
             np.concatenate(batches), g[f'batches_{tag}_flat'])
     assert len(g['batches_32000_sizes']) == 19 and len(g['batches_inf_sizes']) == 1
+
+
+def test_g9_postops_oracle_matches_reference(golden):
+    """distance / sparsify restatements against the reference's own functions
+    (fixture generated by oracle/make_golden_postops.py)."""
+    g = golden('g9_postops')
+    x, y, sim = (torch.from_numpy(g[k]) for k in ('x', 'y', 'similarity'))
+    for normalize in (1, 0):
+        for reduction in ('mean', 'sum', 'none'):
+            out = O.distance(x, y, sim if normalize else None, float(g['exponent']), reduction)
+            ref = torch.from_numpy(np.asarray(g[f'distance_{normalize}_{reduction}']))
+            assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6), (normalize, reduction)
+    batch = torch.from_numpy(g['batch'])
+    assert torch.allclose(O.sparsify(batch, 'percentile', 0.85)[None], torch.from_numpy(g['sparsify_percentile']), atol=1e-6)
+    assert torch.allclose(O.sparsify(batch, 'percentile', 0.5)[None], torch.from_numpy(g['sparsify_percentile_50']), atol=1e-6)
+    assert torch.allclose(O.sparsify(batch, 'constant', 0.1), torch.from_numpy(g['sparsify_constant']), atol=1e-6)
+    assert torch.allclose(O.sparsify(batch[:1], 'topk', 3), torch.from_numpy(g['sparsify_topk3']), atol=1e-6)
+
