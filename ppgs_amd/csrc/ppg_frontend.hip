@@ -304,11 +304,11 @@ hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int bat
     const int frames = samples / HOP;
     const int groups_per_row = (frames + FPB - 1) / FPB;
     const int total = groups_per_row * batch;
-    static int slots = 0;                // resident workgroups of the device; attribute set once (not a stream operation)
+    static LdsLimit limit;
+    const hipError_t e = limit.ensure(reinterpret_cast<const void*>(frontend_kernel), LDS_BYTES);
+    if (e != hipSuccess) return e;
+    static int slots = 0;                // resident workgroups (two per CU; the devices of a node are alike)
     if (slots == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frontend_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)

@@ -1589,12 +1589,9 @@ hipError_t launch_linear_t(const LinearArgs& a, int ypasses, hipStream_t s) {
     const size_t lds = 2 * NB * 16 * 128;
     auto kern = linear_kernel<P, NT, NB, EPI>;
     if (lds > 65536) {
-        static bool configured = false;      // once per process: not a stream operation (graph capture)
-        if (!configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            configured = true;
-        }
+        static ppg::LdsLimit limit;
+        const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(blocks, ypasses), dim3(256), lds, s, a);
     return hipGetLastError();
@@ -1628,14 +1625,11 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const dim3 blocks((a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
     auto kern = ffn_kernel<P, NT, NBH, OP, QKV>;
     const size_t lds = 131072 + (size_t)a.F * 4 + ((OP || QKV) ? 9 : 6) * (size_t)a.H * 4;   // b1, [b2 g2 e2], [bq], [bo g1 e1]
-    static size_t configured = 0;            // once per process and size: not a stream operation
-    if (configured < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static ppg::LdsLimit limit;
+    hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, blocks, dim3(256), lds, s, a);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess || !a.partial) return e;
     hipLaunchKernelGGL(ffn_reduce_ln_kernel<P>, dim3((a.M + 3) / 4), dim3(256), 0, s, a, a.splits);
     return hipGetLastError();
@@ -1651,12 +1645,9 @@ hipError_t launch_ffn_mixed(const FfnArgs& a, hipStream_t s) {
         constexpr int HB = 4;                                  // 16-row blocks of a 64-hidden chunk (hidden 256, bf16)
         // hand-off: 2 wave pairs x 2 buffers x HB KiB of raw accumulators, from the LN1 parameters on
         const size_t lds = 131072 + (size_t)a.F * 4 + 6 * (size_t)a.H * 4 + 2 * 2 * HB * 1024;
-        static size_t configured = 0;
-        if (configured < lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            configured = lds;
-        }
+        static ppg::LdsLimit limit;
+        const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((a.M + 159) / 160), dim3(256), lds, s, a);
         return hipGetLastError();
     }

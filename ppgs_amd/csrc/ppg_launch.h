@@ -22,6 +22,21 @@ hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, 
 
 constexpr int kMaxMelWeights = 1536;   // LDS room for the packed filterbank (1001 non-zeros + interior zeros)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and not a stream
+// operation (it must stay out of graph capture): done once per (kernel
+// instantiation, device) -- again only if a later launch needs more.
+struct LdsLimit {
+    size_t bytes[32] = {};
+    hipError_t ensure(const void* kernel, size_t lds) {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 32) device = 0;
+        if (bytes[device] >= lds) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) bytes[device] = lds;
+        return e;
+    }
+};
+
 struct FrontendTables {
     const float* hann;        // [1024]
     const float2* twiddle;    // [1024] exp(-2 pi i j / 1024)
