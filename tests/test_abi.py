@@ -113,3 +113,19 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     import ppgs_amd
     with pytest.raises(E.PpgError):
         ppgs_amd.from_audio(torch.zeros(1, 1, 16000), 16000)
+    # the satellites of the path have no CPU route either
+    dummy = ctypes.c_void_p(16)
+    assert lib.ppg_resample(0, dummy, 1, 48000, 48000, 16000, dummy, None) == -2
+    assert b'no HIP device' in lib.ppg_last_error()
+    assert lib.ppg_distance(0, dummy, dummy, 10, None, dummy, None) == -2
+    assert lib.ppg_sparsify(0, dummy, 1, 10, 1, 0.85, dummy, None) == -2
+    with pytest.raises(E.PpgError):
+        ppgs_amd.distance(torch.rand(40, 5), torch.rand(40, 5), normalize=False)
+
+
+def test_resample_length_host_helper():
+    lib = E.library()
+    import math
+    for samples, rate in ((48000, 48000), (44100, 44100), (12345, 22050), (1, 8000), (160001, 16001)):
+        assert lib.ppg_resample_length(samples, rate, 16000) == math.ceil(16000 * samples / rate)
+    assert lib.ppg_resample_length(-1, 48000, 16000) == -1
