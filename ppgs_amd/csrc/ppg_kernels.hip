@@ -321,27 +321,29 @@ __device__ __forceinline__ void stage_params(float* lds, int H, int tid, const f
 // (unpinned, it spills most of the accumulators to scratch while they are
 // being computed and the chunk loop runs 15 % slower; pinning xf as well costs
 // 12 % -- measured, PPG_FFN_TIMING).
+// Residual row of the wave's token block t (lane: token idx, features of lane group g)
+template <int NB>
+__device__ __forceinline__ void load_residual_rows(float4 (&rv)[NB], const float* X, int H, int m, int M, int g) {
+    const float* xrow = X + (size_t)(m < M ? m : 0) * H;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        rv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M) rv[nb] = *reinterpret_cast<const float4*>(xrow + pair_feature(nb, g));
+    }
+}
+
 template <class P, int NB, int NT, int XG, int NTX>
 __device__ __forceinline__ void ln_keep(
     f32x4 (&acc)[NB][NT], u32x4 (&xf)[XG][NTX], const float* lnp, const float* X, int H,
-    int tok0, int M, int idx, int g)
+    int tok0, int M, int idx, int g, float4 (&rcur)[NB] /* rows of block 0, loaded by the caller */)
 {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[nb][t]));
     // residual rows: block t+1 is loaded while block t is normalised
-    auto load_rows = [&](int t, float4 (&rv)[NB]) {
-        const int m = tok0 + 16 * t + idx;
-        const float* xrow = X + (size_t)(m < M ? m : 0) * H;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            rv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M) rv[nb] = *reinterpret_cast<const float4*>(xrow + pair_feature(nb, g));
-        }
-    };
-    float4 rcur[NB], rnext[NB];
-    load_rows(0, rcur);
+    auto load_rows = [&](int t, float4 (&rv)[NB]) { load_residual_rows<NB>(rv, X, H, tok0 + 16 * t + idx, M, g); };
+    float4 rnext[NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t + 1 < NT) load_rows(t + 1, rnext);
@@ -993,10 +995,12 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         // are uploaded in the matching order).  x1 also stays in the y
         // accumulators: the FFN sums on top of it, so the second residual
         // costs no memory traffic at all.
+        float4 res0[NBH];        // LN1's residual rows of block 0: fetched under the last W_o tile's MFMAs
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
                 dma_wait_barrier();
                 pstamp(1 + 2 * I);
+                if constexpr (I == OT - 1) load_residual_rows<NBH>(res0, a.X, H, tok0 + idx, a.M, g);
                 phase_a_into(I, yacc, std::integral_constant<int, I * HB>{}, std::integral_constant<int, NTB>{}, [](auto) {});
                 __syncthreads();              // buffer I & 1 is free for the tile after next
                 if constexpr (I + 2 < OT) stage_wo(I + 2);
@@ -1004,7 +1008,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
                 pstamp(2 + 2 * I);
             }(), ...);
         }(std::make_integer_sequence<int, OT>{});
-        ln_keep<P, NBH, NT, XG, NTX>(yacc, xf, lnp1, a.X, H, tok0, a.M, idx, g);
+        ln_keep<P, NBH, NT, XG, NTX>(yacc, xf, lnp1, a.X, H, tok0, a.M, idx, g, res0);
         pstamp(12);
         // yacc keeps x1: phase B accumulates W2 h on top of the residual
         if constexpr (ROLE == 1) {
