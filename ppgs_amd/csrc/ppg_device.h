@@ -221,9 +221,17 @@ struct FfnArgs {
     int splits;
 };
 
+// One attention workgroup's work: a query tile of one window.  The window fields
+// the kernel needs ride along (one 32-byte load instead of item -> window, two
+// dependent round trips at the head of every workgroup).
 struct AttnItem {
     int window;
     int q0;                   // first query (window-relative) of the block's tile
+    int tok_off;              // copies of the PpgWindow fields of `window`
+    int vt_off;
+    int frames;
+    int valid;
+    int pad0, pad1;
 };
 
 struct AttnArgs {

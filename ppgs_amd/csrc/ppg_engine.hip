@@ -85,7 +85,8 @@ void split_groups(Plan* plan, int ngroups, int qtile) {
             win.vt_off -= base_vt;
             const int wi = (int)grp.windows.size();
             for (int k = 0; k < round_up(win.frames, 16) / 16; ++k) grp.blk_win.push_back(wi);
-            for (int q0 = 0; q0 < win.frames; q0 += qtile) grp.items.push_back(AttnItem{wi, q0});
+            for (int q0 = 0; q0 < win.frames; q0 += qtile)
+                grp.items.push_back(AttnItem{wi, q0, win.tok_off, win.vt_off, win.frames, win.valid, 0, 0});
             grp.tokens = win.tok_off + round_up(win.frames, 16);
             grp.vt_tokens = win.vt_off + round_up(win.frames, 32);
             grp.windows.push_back(win);

@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const int idx = lane & 15;
     const int g = lane >> 4;
     const AttnItem item = a.items[blockIdx.x];
-    const PpgWindow w = a.win[item.window];
+    const struct { int tok_off, vt_off, frames, valid; } w = {item.tok_off, item.vt_off, item.frames, item.valid};
     const int head = blockIdx.y;
     const int qw0 = item.q0 + wave * 16 * NTQ;      // first query of this wave
 
