@@ -32,7 +32,7 @@ constexpr int PADR = (NFFT - HOP) / 2;        // 432
 constexpr int FPB = 8;                        // frames per group (4 pairs = 4 waves)
 constexpr int SEG = NFFT + (FPB - 1) * HOP;   // 2144 samples
 constexpr int BUF = NFFT + NFFT / 16;         // exchange buffer entries: index i lives at i + (i >> 4)
-constexpr int MAGLD = 520;                    // floats per magnitude row
+constexpr int MAGLD = 520;                    // (frame A, frame B) magnitude pairs per wave
 
 // LDS map (bytes)
 constexpr int OFF_TW = 0;                                   // float2[1024]
@@ -40,7 +40,7 @@ constexpr int OFF_MELW = OFF_TW + NFFT * 8;                 // float[kMaxMelWeig
 constexpr int OFF_META = OFF_MELW + ppg::kMaxMelWeights * 4;    // int start[80], count[80], offset[80], task[160]
 constexpr int OFF_SEG = OFF_META + (3 * NMELS + 2 * NMELS) * 4;
 constexpr int OFF_FFT = OFF_SEG + SEG * 4;                  // float2[4][BUF]
-constexpr int OFF_MAG = OFF_FFT + 4 * BUF * 8;              // float[4][2][MAGLD]
+constexpr int OFF_MAG = OFF_FFT + 4 * BUF * 8;              // float2[4][MAGLD]: both frames of a pair side by side
 constexpr int OFF_OUT = OFF_MAG + 4 * 2 * MAGLD * 4;        // __half[80][8]
 constexpr int LDS_BYTES = OFF_OUT + NMELS * FPB * 2;
 static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     float2* buf = reinterpret_cast<float2*>(smem + OFF_FFT) + wave * BUF;
-    float* mag = reinterpret_cast<float*>(smem + OFF_MAG) + wave * 2 * MAGLD;
+    float2* mag = reinterpret_cast<float2*>(smem + OFF_MAG) + wave * MAGLD;
 
     for (int i = tid; i < NFFT; i += 256) tw[i] = tb.twiddle[i];
-    if (lane < MAGLD - NBINS) { mag[NBINS + lane] = 0.f; mag[MAGLD + NBINS + lane] = 0.f; }
+    if (lane < MAGLD - NBINS) mag[NBINS + lane] = make_float2(0.f, 0.f);
     for (int i = tid; i < tb.mel_weights; i += 256) melw[i] = tb.mel_weight[i];
     if (tid < NMELS) { mstart[tid] = tb.mel_start[tid]; mcount[tid] = tb.mel_count[tid]; moffset[tid] = tb.mel_offset[tid]; }
     if (tid < NMELS) mtask[tid] = tb.mel_task[tid];
@@ -240,8 +240,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                 // denormal handling, and the result is rounded to fp16 next
                 const __half ha = __float2half_rn(__builtin_amdgcn_sqrtf(ar * ar + ai * ai + 1e-6f));
                 const __half hb = __float2half_rn(__builtin_amdgcn_sqrtf(br * br + bi * bi + 1e-6f));
-                mag[k] = __half2float(ha);
-                mag[MAGLD + k] = __half2float(hb);
+                mag[k] = make_float2(__half2float(ha), __half2float(hb));
                 if (spec) {
                     spec[((size_t)b * NBINS + k) * frames + fa] = ha;
                     if (fa + 1 < frames) spec[((size_t)b * NBINS + k) * frames + fa + 1] = hb;
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                         const int m = mtask[slot];
                         const int count = mcount[m];
                         const float4* wt = reinterpret_cast<const float4*>(melw + moffset[m]);   // rows are 32-byte aligned
-                        const float* mg = mag + mstart[m];
+                        const float2* mg = mag + mstart[m];
                         // sequential sums (the order of the oracle's sparse rows); filter rows are
                         // zero-padded to multiples of 8 bins by the host so that 8 terms share one
                         // LDS round trip (magnitude rows end in 7 zeroed pad floats)
@@ -270,11 +269,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                         for (int i = 0; i < count; i += 8) {
                             const float4 wa = wt[i / 4], wb = wt[i / 4 + 1];
                             const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-                            float g0[8], g1[8];
+                            float2 gm[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) { g0[u] = mg[i + u]; g1[u] = mg[MAGLD + i + u]; }
+                            for (int u = 0; u < 8; ++u) gm[u] = mg[i + u];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) { acc0 += w[u] * g0[u]; acc1 += w[u] * g1[u]; }
+                            for (int u = 0; u < 8; ++u) { acc0 += w[u] * gm[u].x; acc1 += w[u] * gm[u].y; }
                         }
                         melout[m * FPB + 2 * wave] = __float2half_rn(logf(fmaxf(acc0, 1e-5f)));
                         melout[m * FPB + 2 * wave + 1] = __float2half_rn(logf(fmaxf(acc1, 1e-5f)));
