@@ -217,11 +217,19 @@ int ppg_resample(int device, const float* audio, int batch, int64_t samples,
  *   threshold.  ppg, out: device fp32 (batch, 40, frames);  method 0 =
  *   'constant', 1 = 'percentile' (threshold = quantile in [0, 1]), 2 = 'topk'
  *   (threshold = k).
+ * ppg_grid_sample: replaces ppgs.edit.grid.sample (ppgs/edit/grid.py:13-45),
+ *   time-stretching by fractional frame indices.  ppg: device fp32 (rows,
+ *   frames), rows = every leading dimension flattened;  grid: device fp32
+ *   (length) indices into the frames;  out: device fp32 (rows, length) =
+ *   linear interpolation between the two neighbouring frames, the last frame
+ *   repeated once past the end.
  */
 int ppg_distance(int device, const float* ppg_x, const float* ppg_y, int frames,
                  const float* mix, float* jsd, void* stream);
 int ppg_sparsify(int device, const float* ppg, int batch, int frames, int method,
                  float threshold, float* out, void* stream);
+int ppg_grid_sample(int device, const float* ppg, int rows, int frames,
+                    const float* grid, int length, float* out, void* stream);
 
 /*
  * Per-kernel-class timing with HIP events on the launch stream (used by

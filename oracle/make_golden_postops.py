@@ -1,5 +1,6 @@
 """Golden vectors for the PPG post-ops: the reference's own
-ppgs.distance / ppgs.sparsify / ppgs.interpolate (ppgs/core.py:399-543), imported
+ppgs.distance / ppgs.sparsify / ppgs.interpolate (ppgs/core.py:399-543) and
+ppgs.edit.grid.sample / constant / of_length (ppgs/edit/grid.py), imported
 here with third-party stubs and run on seeded posteriorgrams.
 
     python oracle/make_golden_postops.py        # writes tests/golden/g9_postops.npz
@@ -48,6 +49,19 @@ def main():
     out['sparsify_constant'] = core.sparsify(batch.clone(), 'constant', torch.tensor([0.1]))
     single = batch[:1].clone()
     out['sparsify_topk3'] = core.sparsify(single.clone(), 'topk', 3)
+    # time-stretching (ppgs/edit/grid.py); pypar is only used by from_alignments
+    pypar = types.ModuleType('pypar')
+    pypar.Alignment = object            # annotation only
+    sys.modules['pypar'] = pypar
+    ppgs.interpolate = core.interpolate
+    grid = G._load('ppgs.edit.grid', os.path.join(G.REF, 'ppgs', 'edit', 'grid.py'))
+    out['grid_slow'] = grid.constant(x, 0.7)
+    out['grid_fast'] = grid.of_length(x, 23)
+    out['grid_edges'] = torch.tensor([0., 0.25, 1., 13.5, 55.999, 56., 56.4, 57., 80., -0.25, -3.5])
+    for name in ('slow', 'fast', 'edges'):
+        out[f'sample_{name}'] = grid.sample(x, out[f'grid_{name}'])
+    out['sample_batch'] = grid.sample(batch, grid.of_length(batch, 50))
+    out['sample_half'] = grid.sample(x.half(), out['grid_slow']).float()
     G.save('g9_postops', **out)
     for key, value in out.items():
         if isinstance(value, torch.Tensor):

@@ -374,3 +374,14 @@ def sparsify(ppg, method='percentile', threshold=0.85):
         raise ValueError(method)
     return torch.softmax(torch.log(ppg + 1e-8), -2)
 
+
+
+def grid_sample(ppg, grid):
+    """Reference ppgs/edit/grid.py:13-45: (..., frames) at fractional frame
+    indices grid (length,) -> (..., length)."""
+    frames = ppg.shape[-1]
+    low = torch.floor(grid)
+    weight = grid - low
+    upper = torch.where(grid < 0, torch.zeros_like(low), low + 1).clamp(max=frames).long()
+    extended = torch.cat([ppg, ppg[..., -1:]], dim=-1)          # final frame replicated
+    return (1. - weight) * extended[..., upper - 1] + weight * extended[..., upper]

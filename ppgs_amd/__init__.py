@@ -12,6 +12,6 @@ from .core import (                   # noqa: F401
     from_files_to_files, from_dataloader, infer, resample,
     distance, interpolate, sparsify,
     representation_file_extension, engine_for, clear_cache)
-from . import core, distributed      # noqa: F401
+from . import core, distributed, edit      # noqa: F401
 
 __version__ = '0.1.0'

@@ -1,5 +1,6 @@
 // PPG post-ops on the device: the per-frame arithmetic of
-// reference ppgs.distance (ppgs/core.py:399-472) and ppgs.sparsify (:510-543).
+// reference ppgs.distance (ppgs/core.py:399-472) and ppgs.sparsify (:510-543),
+// and the time-stretch gather of ppgs.edit.grid.sample (ppgs/edit/grid.py:13-45).
 // 40 phonemes per frame: one thread per frame, everything in registers (all
 // loops over the 40 channels are fully unrolled), reads and writes coalesced
 // over frames.  HBM-trivial: 160 B in per posteriorgram frame.
@@ -103,6 +104,35 @@ __global__ __launch_bounds__(64) void sparsify_kernel(const float* __restrict__ 
     for (int p = 0; p < NP; ++p) dst[(size_t)p * frames] = v[p] * inv;
 }
 
+// out[r, g] = (1 - w) * ppg[r, lo] + w * ppg[r, hi] for the fractional frame index
+// grid[g] (ppgs/edit/grid.py:13-45): hi = #{frames <= grid[g]} (searchsorted
+// 'right' over 0..frames-1), lo = hi - 1, w = grid - floor(grid); the PPG is
+// extended by one copy of its last frame, and lo = -1 (a negative grid value)
+// indexes from the end like the reference's tensor indexing does, i.e. that copy.
+// One thread per output frame, looping over the rows it is given: consecutive
+// lanes read (nearly) consecutive frames of a row for any monotone grid.
+__global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restrict__ ppg, int rows, int frames,
+                                                          const float* __restrict__ grid, int length,
+                                                          float* __restrict__ out) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= length) return;
+    const float x = grid[g];
+    const float fl = floorf(x);
+    const float w = x - fl;
+    int hi = x < 0.f ? 0 : (fl >= (float)frames ? frames : (int)fl + 1);
+    if (!(x == x)) hi = frames;                       // NaN sorts after every frame
+    int lo = hi - 1;
+    if (lo < 0) lo = frames;                          // index -1 of the extended PPG
+    const int last = frames - 1;
+    lo = lo > last ? last : lo;                       // the extra frame is the last one again
+    hi = hi > last ? last : hi;
+    const float u = 1.f - w;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float* src = ppg + (size_t)r * frames;
+        out[(size_t)r * length + g] = __fadd_rn(__fmul_rn(u, src[lo]), __fmul_rn(w, src[hi]));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -128,6 +158,18 @@ int ppg_sparsify(int device, const float* ppg, int batch, int frames, int method
                        ppg, frames, method, threshold, out);
     const hipError_t he = hipGetLastError();
     return he == hipSuccess ? PPG_OK : ppg::fail_message(PPG_EDEVICE, "sparsify: %s", hipGetErrorString(he));
+}
+
+int ppg_grid_sample(int device, const float* ppg, int rows, int frames, const float* grid, int length,
+                    float* out, void* stream) {
+    if (!ppg || rows <= 0 || frames <= 0 || length < 0 || (length > 0 && (!grid || !out)))
+        return ppg::fail_message(PPG_EINVAL, "grid_sample: bad argument");
+    if (hipSetDevice(device) != hipSuccess) return ppg::fail_message(PPG_EDEVICE, "no HIP device: the post-ops have no CPU path");
+    if (length == 0) return PPG_OK;
+    hipLaunchKernelGGL(grid_sample_kernel, dim3((length + 255) / 256, rows < 4096 ? rows : 4096), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ppg, rows, frames, grid, length, out);
+    const hipError_t he = hipGetLastError();
+    return he == hipSuccess ? PPG_OK : ppg::fail_message(PPG_EDEVICE, "grid_sample: %s", hipGetErrorString(he));
 }
 
 }  // extern "C"

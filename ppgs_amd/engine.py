@@ -94,6 +94,9 @@ SYMBOLS = {
     'ppg_sparsify': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_grid_sample': (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'ppg_engine_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'ppg_engine_profile_read': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
@@ -427,6 +430,27 @@ def sparsify(ppg, method, threshold):
             x.device.index, x.data_ptr(), x.shape[0], x.shape[2], int(method),
             float(threshold), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
     return out
+
+
+def grid_sample(ppg, grid):
+    """(..., frames) on a GPU sampled at the fractional frame indices `grid`
+    (length,) -> (..., length) (ppg_grid_sample)."""
+    if not ppg.is_cuda:
+        raise PpgError('ppgs_amd: the post-ops work on HIP device tensors')
+    if grid.dim() != 1:
+        raise ValueError(f'grid must be one-dimensional, got {tuple(grid.shape)}')
+    if ppg.dim() < 1 or ppg.shape[-1] < 1:
+        raise ValueError(f'PPG must be (..., frames >= 1), got {tuple(ppg.shape)}')
+    x = ppg.to(torch.float32).contiguous()
+    g = grid.to(device=x.device, dtype=torch.float32).contiguous()
+    out = torch.empty(x.shape[:-1] + (g.shape[0],), dtype=torch.float32, device=x.device)
+    rows = x.numel() // x.shape[-1]
+    if rows and g.shape[0]:
+        with torch.cuda.device(x.device):
+            _check(library().ppg_grid_sample(
+                x.device.index, x.data_ptr(), rows, x.shape[-1], g.data_ptr(),
+                g.shape[0], out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return out      # fp32 also for half-precision PPGs: the reference's float grid promotes them
 
 
 def frontend_profile(device, enable=True):

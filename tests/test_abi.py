@@ -119,6 +119,7 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     assert b'no HIP device' in lib.ppg_last_error()
     assert lib.ppg_distance(0, dummy, dummy, 10, None, dummy, None) == -2
     assert lib.ppg_sparsify(0, dummy, 1, 10, 1, 0.85, dummy, None) == -2
+    assert lib.ppg_grid_sample(0, dummy, 40, 10, dummy, 5, dummy, None) == -2
     with pytest.raises(E.PpgError):
         ppgs_amd.distance(torch.rand(40, 5), torch.rand(40, 5), normalize=False)
 

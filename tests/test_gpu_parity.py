@@ -137,6 +137,30 @@ def test_postops_match_reference_fixture(golden):
         ppgs_amd.sparsify(batch, 'median')
 
 
+def test_grid_sample_matches_reference_fixture(golden):
+    """ppgs_amd.edit.grid.sample on the GPU against the reference's own
+    ppgs.edit.grid.sample (fixture g9): bit-exact -- two products and a sum per
+    output value, no contraction.  'edges' holds exact-integer, past-the-end and
+    negative indices; then a long random grid against the oracle."""
+    from ppgs_amd.edit import grid
+    g = golden('g9_postops')
+    x, batch = t(g['x']).cuda(), t(g['batch']).cuda()
+    for name in ('slow', 'fast', 'edges'):
+        out = grid.sample(x, t(g[f'grid_{name}']))
+        assert out.is_cuda and np.array_equal(out.cpu().numpy(), g[f'sample_{name}']), name
+    assert np.array_equal(grid.sample(batch, grid.of_length(batch, 50)).cpu().numpy(), g['sample_batch'])
+    half = grid.sample(x.half(), t(g['grid_slow']).cuda())
+    assert half.dtype == torch.float32 and np.array_equal(half.cpu().numpy(), g['sample_half'])
+    assert torch.equal(grid.constant(x, 0.7).cpu(), t(g['grid_slow'])) and grid.constant(x, 0.7).is_cuda
+    assert grid.sample(x, torch.zeros(0)).shape == (40, 0)
+    gen = torch.Generator().manual_seed(11)
+    ppg = torch.softmax(torch.randn(3, 40, 2999, generator=gen), dim=1)
+    index = torch.rand(7001, generator=gen) * 3010 - 5
+    assert torch.equal(grid.sample(ppg.cuda(), index).cpu(), O.grid_sample(ppg, index))
+    with pytest.raises(ValueError):
+        grid.sample(x, torch.zeros(2, 2))
+
+
 # ------------------------------------------------------------------- model --
 
 @pytest.mark.parametrize('layers', [0, 1])
