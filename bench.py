@@ -36,6 +36,7 @@ import torch.distributed as dist                         # noqa: E402
 BATCH = 32
 FRAMES = 1000
 SAMPLES = FRAMES * 160
+EVENT_STRIDE = 6               # roofline leg: HIP events around every 6th layer-kernel launch of the timed region
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_FP32_TFLOPS = 157.3
 
@@ -150,7 +151,10 @@ def main():
     assert out.shape == (BATCH, 40, FRAMES) and bool(torch.isfinite(out).all())
 
     # timed region: HIP events only around the dominant kernel (roofline leg)
-    model.profile(True, classes=['ffn'])
+    # (every 6th launch: 6 is coprime with the 5 layers, so the samples rotate
+    # through the five launches of a step; two event records per launch cost
+    # ~1.5 us each on the stream, 1.5 % of the step if every launch is timed)
+    model.profile(True, classes=['ffn'], stride=EVENT_STRIDE)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,7 +169,7 @@ def main():
         worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         elapsed = float(worst.item())
-    ffn_ms, ffn_launches = model.profile_read()['ffn']
+    ffn_ms, ffn_samples = model.profile_read()['ffn']
     # untimed extra pass: per-kernel-class breakdown (events around every launch)
     breakdown_steps = 5
     model.profile(True)
@@ -185,7 +189,7 @@ def main():
         hidden, ffn = 256, 2048
         # FLOPs of ONE launch: the batch's FFN work of one layer, divided by the
         # launches per layer (>1 when the engine splits the batch over streams)
-        launches_per_layer = max(ffn_launches // (5 * args.steps), 1)
+        launches_per_layer = max(kernels['ffn'][1] // (5 * breakdown_steps), 1)
         # (FFN 2*2*H*F per processed frame; the attention
         # out-projection's 2*H*H ride along when the engine fuses it into the
         # same kernel -- then no separate out-proj launch shows up)
@@ -200,7 +204,7 @@ def main():
         flops_per_frame = (4.0 * hidden * ffn + (2.0 * hidden * hidden if op_fused else 0.0)
                            + 6.0 * hidden * hidden * qkv_fused_layers / layers)
         ffn_flops = flops_per_frame * info.processed_frames / launches_per_layer
-        ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_launches, 1)) / 1e12
+        ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_samples, 1)) / 1e12
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_FP32_TFLOPS
         step_flops = BATCH * data.flops(FRAMES)
         line = {
@@ -235,7 +239,8 @@ def main():
                 'frac': ffn_tflops / peak,
                 'traffic': pmc_traffic(),
                 'flops_per_launch': ffn_flops,
-                'mean_launch_ms': ffn_ms / max(ffn_launches, 1),
+                'mean_launch_ms': ffn_ms / max(ffn_samples, 1),
+                'timed_launches': ffn_samples,
             },
             'end_to_end_tflops': step_flops * args.steps / elapsed / 1e12,
             'end_to_end_mfma_frac': step_flops * args.steps / elapsed / 1e12 / peak,

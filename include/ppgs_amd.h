@@ -237,11 +237,14 @@ int ppg_grid_sample(int device, const float* ppg, int rows, int frames,
  * off, -1 = every class (each timed launch costs two event records on the
  * stream).  Enable, run, then read: total milliseconds and launch count
  * accumulated since the last reset.  Reading synchronises the recorded events.
+ * ppg_engine_profile_stride(n): time only every n-th launch of each enabled
+ * class (n = 1: all); `launches` then counts the timed ones.
  */
 int ppg_engine_profile(PpgEngine* engine, int classes);
 int ppg_engine_profile_read(PpgEngine* engine, int kernel_class,
                             double* total_ms, int64_t* launches);
 int ppg_engine_profile_reset(PpgEngine* engine);
+int ppg_engine_profile_stride(PpgEngine* engine, int stride);
 int ppg_frontend_profile(int device, int enable);
 int ppg_frontend_profile_read(int device, double* total_ms, int64_t* launches);
 

@@ -238,6 +238,8 @@ struct PpgEngine {
     unsigned profiling = 0;          // bitmask of kernel classes to time
     std::vector<EventPair> events[PPG_K_COUNT];
     size_t events_used[PPG_K_COUNT] = {0};
+    int profile_stride = 1;                    // time every stride-th launch of a class
+    size_t launch_seq[PPG_K_COUNT] = {0};
 
     ~PpgEngine() {
         (void)hipSetDevice(device);
@@ -487,6 +489,7 @@ struct Timed {
     PpgEngine* e; int cls; hipStream_t s; EventPair ev{}; bool on = false;
     Timed(PpgEngine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
         if (!(e->profiling & (1u << cls))) return;
+        if (e->launch_seq[cls]++ % (size_t)e->profile_stride) return;
         auto& pool = e->events[cls];
         size_t& used = e->events_used[cls];
         if (used == pool.size()) {
@@ -1035,6 +1038,13 @@ int ppg_engine_profile(PpgEngine* e, int enable) {
 int ppg_engine_profile_reset(PpgEngine* e) {
     if (!e) return fail(PPG_EINVAL, "null engine");
     for (auto& u : e->events_used) u = 0;
+    for (auto& q : e->launch_seq) q = 0;
+    return PPG_OK;
+}
+
+int ppg_engine_profile_stride(PpgEngine* e, int stride) {
+    if (!e || stride < 1) return fail(PPG_EINVAL, "profile stride must be >= 1");
+    e->profile_stride = stride;
     return PPG_OK;
 }
 

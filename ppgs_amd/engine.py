@@ -102,6 +102,7 @@ SYMBOLS = {
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
         _I64P]),
     'ppg_engine_profile_reset': (ctypes.c_int, [ctypes.c_void_p]),
+    'ppg_engine_profile_stride': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'ppg_frontend_profile': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     'ppg_frontend_profile_read': (ctypes.c_int, [
         ctypes.c_int, ctypes.POINTER(ctypes.c_double), _I64P]),
@@ -326,9 +327,11 @@ class Engine:
         return run
 
     # -- per-kernel HIP-event timing (bench.py roofline leg) ----------------
-    def profile(self, enable=True, classes=None):
+    def profile(self, enable=True, classes=None, stride=1):
         """Time launches with HIP events: every kernel class, or only the
-        named ones (each timed launch adds two event records to the stream)."""
+        named ones (each timed launch adds two event records to the stream);
+        stride n times every n-th launch of a class only."""
+        _check(self._lib.ppg_engine_profile_stride(self._handle, int(stride)))
         mask = 0
         if enable:
             mask = -1 if classes is None else sum(
