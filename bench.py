@@ -127,9 +127,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # (PPGS_BENCH_FORCE_DIST=1: exercise the RCCL barrier / max-over-ranks path with one rank)
+    use_dist = world > 1 or bool(os.environ.get('PPGS_BENCH_FORCE_DIST'))
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
 
     import ppgs_amd
     from ppgs_amd import data, engine as E
@@ -155,17 +159,17 @@ def main():
     # through the five launches of a step; two event records per launch cost
     # ~1.5 us each on the stream, 1.5 % of the step if every launch is timed)
     model.profile(True, classes=['ffn'], stride=EVENT_STRIDE)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     start = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - start
-    if world > 1:
+    if use_dist:
         worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         elapsed = float(worst.item())
@@ -251,7 +255,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
             line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
