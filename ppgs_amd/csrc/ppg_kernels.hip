@@ -1323,10 +1323,24 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
         const float4 bv = *reinterpret_cast<const float4*>(a.b2 + n);
         const float4 xv = *reinterpret_cast<const float4*>(a.X + (size_t)m * H + n);
         float4 acc = make_float4(bv.x + xv.x, bv.y + xv.y, bv.z + xv.z, bv.w + xv.w);
-        for (int sidx = 0; sidx < splits; ++sidx) {
-            const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)sidx * a.M + m) * H + n);
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-        }
+        // the partial sums are added in split order, loaded 8 / 4 / 1 at a time:
+        // one load latency per batch instead of one per split
+        const float* part = a.partial + (size_t)m * H + n;
+        const size_t stride = (size_t)a.M * H;
+        int sidx = 0;
+        auto batch = [&](auto count) {
+            constexpr int N = decltype(count)::value;
+            for (; sidx + N <= splits; sidx += N) {
+                float4 p[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) p[j] = *reinterpret_cast<const float4*>(part + (size_t)(sidx + j) * stride);
+#pragma unroll
+                for (int j = 0; j < N; ++j) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
+            }
+        };
+        batch(std::integral_constant<int, 8>{});
+        batch(std::integral_constant<int, 4>{});
+        batch(std::integral_constant<int, 1>{});
         v[h] = acc;
         sum += (acc.x + acc.y) + (acc.z + acc.w);
     }
