@@ -214,6 +214,7 @@ struct PpgEngine {
     int num_cus = 256;
     bool ffn_fused = true;
     bool qkv_fused = true;   // next layer's Q/K/V projection as the tail of the fused FFN kernel (PPGS_AMD_QKV_FUSED=0: own kernel)
+    int ffn_split_max = 0;   // PPGS_AMD_FFN_SPLIT_MAX: cap on the hidden splits (0: half the chunks)
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
@@ -367,7 +368,8 @@ void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) 
         // frames, 54 tiles: 500 us/step unsplit vs 576 us split)
         if (tiles_max_nt * 8 <= e->num_cus) {
             nt = max_nt;
-            while (splits * 2 <= chunks / 2 && tiles_max_nt * splits * 2 <= e->num_cus) splits *= 2;
+            const int cap = e->ffn_split_max > 0 ? e->ffn_split_max : chunks / 2;
+            while (splits * 2 <= cap && tiles_max_nt * splits * 2 <= e->num_cus) splits *= 2;
         }
     }
     // mixed tiling (160-token workgroups, ppg_kernels.hip ffn_mixed_kernel): 2.5 blocks of
@@ -683,6 +685,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     }
     if (const char* v = getenv("PPGS_AMD_OP_FUSED")) e->op_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_FFN_MIXED")) e->ffn_mixed = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_FFN_SPLIT_MAX")) e->ffn_split_max = atoi(v);
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
