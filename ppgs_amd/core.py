@@ -314,39 +314,22 @@ def infer(features, lengths, representation='mel', checkpoint=None,
 def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
     """Perform audio resampling (reference ppgs/core.py:599-608).
 
-    Identity at 16 kHz.  Otherwise a windowed-sinc polyphase filter with
-    torchaudio.transforms.Resample's defaults (Hann window,
-    lowpass_filter_width 6, rolloff 0.99) -- restated from the published
-    algorithm; torchaudio is absent here, so this branch is parity-unpinned.
+    Identity at 16 kHz.  Otherwise torchaudio.transforms.Resample's default
+    windowed-sinc polyphase filter (Hann window, lowpass_filter_width 6,
+    rolloff 0.99), executed by the HIP kernel ``ppg_resample`` -- the ONE
+    implementation in this package (torchaudio is absent in the build image:
+    the kernel follows its published algorithm and is tested against a fixture
+    computed from the closed-form filter in float64, tests/golden/g10).  Host
+    tensors (file loading) make the round trip through the current HIP device
+    and come back on the host, like every other entry point of an engine
+    without a CPU path.
     """
     if sample_rate == target_rate:
         return audio
-    if audio.is_cuda:                       # device tensors: the HIP kernel (ppg_resample)
+    if audio.is_cuda:
         return engine.resample(audio, sample_rate, target_rate)
-    # host tensors (file loading before the H2D copy): the same filter in torch
-    orig, new = int(sample_rate), int(target_rate)
-    gcd = math.gcd(orig, new)
-    orig, new = orig // gcd, new // gcd
-    lowpass_filter_width, rolloff = 6, 0.99
-    base_freq = min(orig, new) * rolloff
-    width = math.ceil(lowpass_filter_width * orig / base_freq)
-    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
-    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
-    t = (t * base_freq).clamp(-lowpass_filter_width, lowpass_filter_width)
-    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
-    t = t * math.pi
-    scale = base_freq / orig
-    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
-    kernels = (kernels * window * scale).to(torch.float32)
-    shape = audio.shape
-    flat = audio.reshape(-1, shape[-1]).to(torch.float32)
-    length = flat.shape[-1]
-    padded = torch.nn.functional.pad(flat, (width, width + orig))
-    out = torch.nn.functional.conv1d(
-        padded[:, None].to(kernels.device), kernels, stride=orig)
-    out = out.transpose(1, 2).reshape(flat.shape[0], -1)
-    target_length = math.ceil(new * length / orig)
-    return out[..., :target_length].reshape(shape[:-1] + (target_length,))
+    device = device_for(None)
+    return engine.resample(audio.to(device), sample_rate, target_rate).cpu()
 
 
 ###############################################################################
@@ -354,24 +337,49 @@ def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
 ###############################################################################
 
 
+_similarity_cache = {}
+
+
 def similarity_matrix(device=None):
     """The reference's 40 x 40 phoneme similarity matrix
-    (ppgs.SIMILARITY_MATRIX_PATH, a data asset of the reference package).  It is
-    not part of this package: taken from PPGS_AMD_SIMILARITY_MATRIX (a .pt file
-    holding the tensor) or, if the reference package is importable, from it."""
+    (ppgs.SIMILARITY_MATRIX_PATH, a data asset of the reference package, not of
+    this one): read from the .pt file PPGS_AMD_SIMILARITY_MATRIX names (a bare
+    tensor, loaded with weights_only=True) and cached per path.  Without it,
+    pass ``similarity=`` to :func:`distance`."""
     path = os.environ.get('PPGS_AMD_SIMILARITY_MATRIX')
     if path is None:
-        try:
-            import ppgs
-            path = ppgs.SIMILARITY_MATRIX_PATH
-        except Exception as error:
+        raise ValueError(
+            'ppgs_amd.distance(normalize=True) needs the phoneme similarity '
+            'matrix: pass similarity=<(40,40) tensor> or set '
+            'PPGS_AMD_SIMILARITY_MATRIX to the reference\'s '
+            'balanced_similarity.pt')
+    if path not in _similarity_cache:
+        matrix = torch.load(path, map_location='cpu', weights_only=True)
+        if not torch.is_tensor(matrix) or tuple(matrix.shape) != (
+                config.OUTPUT_CHANNELS, config.OUTPUT_CHANNELS):
             raise ValueError(
-                'ppgs_amd.distance(normalize=True) needs the phoneme similarity '
-                'matrix: pass similarity=<(40,40) tensor> or set '
-                'PPGS_AMD_SIMILARITY_MATRIX to the reference\'s '
-                'balanced_similarity.pt') from error
-    matrix = torch.load(path, map_location='cpu')
+                f'{path}: expected a ({config.OUTPUT_CHANNELS}, '
+                f'{config.OUTPUT_CHANNELS}) tensor')
+        _similarity_cache[path] = matrix
+    matrix = _similarity_cache[path]
     return matrix if device is None else matrix.to(device)
+
+
+_mix_cache = {}
+
+
+def _similarity_mix(similarity, exponent, device):
+    """(S.T ** exponent) on the device, cached per (matrix, device, exponent)
+    as the reference caches it per device (ppgs/core.py:432-441)."""
+    key = (id(similarity), similarity._version, str(device), float(exponent))
+    hit = _mix_cache.get(key)
+    if hit is None or hit[0] is not similarity:
+        if len(_mix_cache) > 16:
+            _mix_cache.clear()
+        mix = (similarity.to(device=device, dtype=torch.float32).T
+               ** exponent).contiguous()
+        _mix_cache[key] = hit = (similarity, mix)
+    return hit[1]
 
 
 def distance(ppgX, ppgY, reduction='mean', normalize=True,
@@ -387,7 +395,7 @@ def distance(ppgX, ppgY, reduction='mean', normalize=True,
     if normalize:
         if similarity is None:
             similarity = similarity_matrix()
-        mix = similarity.to(device=device, dtype=torch.float32).T ** exponent
+        mix = _similarity_mix(similarity, exponent, device)
     jsd = engine.distance_frames(ppgX.to(device), ppgY.to(device), mix)
     if reduction == 'mean':
         return jsd.mean(dim=0)
