@@ -37,6 +37,10 @@ enum {
 enum {
     PPG_PRECISION_FP32 = 0, /* f32-input MFMA, parity mode (<=1e-4 vs oracle)  */
     PPG_PRECISION_BF16 = 1, /* bf16 MFMA, fp32 accumulate, throughput mode     */
+    PPG_PRECISION_FP16 = 2, /* fp16 MFMA operands (11-bit significand), fp32 accumulate:
+                               same MFMA rate as bf16, ~8x smaller operand rounding;
+                               operands must stay below 65504 in magnitude (what the
+                               reference's CUDA autocast assumes, ppgs/core.py:586)  */
 };
 
 /* dtype tags for feature tensors handed to ppg_encode */

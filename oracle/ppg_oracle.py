@@ -174,24 +174,33 @@ def num_layers(state):
     return n
 
 
-def window_forward(state, x, clens, is_causal=False, heads=2):
+def window_forward(state, x, clens, is_causal=False, heads=2, quant=None):
     """One unchunked forward, reference transformer.py:65-81.
 
     x: (B, Cin, Tc) fp32; clens: (B,) ints (valid frames per item).
     Every one of the Tc positions is computed, padded ones included.
     Attention follows F.multi_head_attention_forward + SDPA: key-padding mask
     and causal mask are additive -inf; rows whose keys are all masked give 0.
+
+    ``quant(stage, tensor) -> tensor`` (default: identity = the fp32 parity
+    definition) rounds the MFMA OPERANDS of the engine's 16-bit modes at the
+    points where the HIP kernels round them -- 'feat', 'w' (weights), 'x0'
+    (in-conv output as the layer-0 operand), 'qkv', 'p' (softmax numerators),
+    'ao', 'x1' / 'x2' (LayerNorm outputs as operands; the residual stays fp32),
+    'h' -- for the error attribution of tools/precision_attribution.py.
     """
+    q_ = quant if quant is not None else (lambda stage, tensor: tensor)
     B, _, Tc = x.shape
     clens = torch.as_tensor(clens, dtype=torch.long)
     t = torch.arange(Tc)
     mask = t[None, :] < clens[:, None]                          # (B, Tc)
     h = torch.nn.functional.conv1d(
-        x, state['input_layer.weight'], state['input_layer.bias'],
+        q_('feat', x), q_('w', state['input_layer.weight']), state['input_layer.bias'],
         padding='same') * mask[:, None, :]
     H = h.shape[1]
     d = H // heads
     z = h.permute(0, 2, 1) + state['position.encoding'][:Tc, 0][None]   # (B,Tc,H)
+    zop = q_('x0', z)                       # operand copy of the residual stream
 
     bias = torch.zeros(B, 1, Tc, Tc)
     bias = bias.masked_fill(~mask[:, None, None, :], float('-inf'))
@@ -201,8 +210,8 @@ def window_forward(state, x, clens, is_causal=False, heads=2):
 
     for l in range(num_layers(state)):
         p = f'model.layers.{l}.'
-        qkv = z @ state[p + 'self_attn.in_proj_weight'].T + \
-            state[p + 'self_attn.in_proj_bias']
+        qkv = q_('qkv', zop @ q_('w', state[p + 'self_attn.in_proj_weight']).T +
+                  state[p + 'self_attn.in_proj_bias'])
         q, k, v = qkv.split(H, dim=-1)
         q = q.reshape(B, Tc, heads, d).transpose(1, 2)          # (B,h,Tc,d)
         k = k.reshape(B, Tc, heads, d).transpose(1, 2)
@@ -212,47 +221,52 @@ def window_forward(state, x, clens, is_causal=False, heads=2):
         smax = torch.where(torch.isinf(smax), torch.zeros_like(smax), smax)
         e = torch.exp(scores - smax)
         denom = e.sum(dim=-1, keepdim=True)
-        attn = torch.where(denom > 0, e / denom, torch.zeros_like(e))
-        o = (attn @ v).transpose(1, 2).reshape(B, Tc, H)
-        o = o @ state[p + 'self_attn.out_proj.weight'].T + \
+        if quant is None:
+            attn = torch.where(denom > 0, e / denom, torch.zeros_like(e))
+            o = attn @ v
+        else:       # the kernels round the numerators and divide by the fp32 row sum afterwards
+            o = torch.where(denom > 0, (q_('p', e) @ v) / denom, torch.zeros_like(v))
+        o = q_('ao', o.transpose(1, 2).reshape(B, Tc, H))
+        o = o @ q_('w', state[p + 'self_attn.out_proj.weight']).T + \
             state[p + 'self_attn.out_proj.bias']
         z = torch.nn.functional.layer_norm(
             z + o, (H,), state[p + 'norm1.weight'], state[p + 'norm1.bias'],
             LN_EPS)
-        f = torch.relu(
-            z @ state[p + 'linear1.weight'].T + state[p + 'linear1.bias'])
-        f = f @ state[p + 'linear2.weight'].T + state[p + 'linear2.bias']
+        f = q_('h', torch.relu(
+            q_('x1', z) @ q_('w', state[p + 'linear1.weight']).T + state[p + 'linear1.bias']))
+        f = f @ q_('w', state[p + 'linear2.weight']).T + state[p + 'linear2.bias']
         z = torch.nn.functional.layer_norm(
             z + f, (H,), state[p + 'norm2.weight'], state[p + 'norm2.bias'],
             LN_EPS)
+        zop = q_('x2', z)
 
     y = torch.nn.functional.conv1d(
-        z.permute(0, 2, 1), state['output_layer.weight'],
+        zop.permute(0, 2, 1), q_('w', state['output_layer.weight']),
         state['output_layer.bias'], padding='same')
     return y * mask[:, None, :]
 
 
-def forward(state, features, lengths, is_causal=False, legacy_mode=False):
+def forward(state, features, lengths, is_causal=False, legacy_mode=False, quant=None):
     """reference Transformer.forward (transformer.py:45-81) -> logits (B,40,T)."""
     features = features.to(torch.float)
     T = features.shape[-1]
     if legacy_mode or T <= CHUNK_LENGTH:
-        return window_forward(state, features, lengths, is_causal)
+        return window_forward(state, features, lengths, is_causal, quant=quant)
     padded = torch.nn.functional.pad(
         features, (CHUNK_OVERLAP, 0), mode='replicate')
     outputs = []
     for w in plan_windows(T, lengths):
         split = padded[..., w['start']:w['start'] + w['Tc']]
-        out = window_forward(state, split, w['clens'], is_causal)
+        out = window_forward(state, split, w['clens'], is_causal, quant=quant)
         outputs.append(out[..., w['keep_lo']:w['keep_hi']])
     return torch.cat(outputs, dim=-1)
 
 
 def from_features(state, features, lengths, softmax=True, is_causal=False,
-                  legacy_mode=False):
+                  legacy_mode=False, quant=None):
     """reference ppgs.from_features / infer (core.py:72-128, 551-596), fp32."""
     with torch.inference_mode():
-        logits = forward(state, features, lengths, is_causal, legacy_mode)
+        logits = forward(state, features, lengths, is_causal, legacy_mode, quant)
         if softmax:
             return torch.softmax(logits, dim=1)
         return logits

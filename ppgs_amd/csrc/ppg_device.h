@@ -29,6 +29,7 @@
 #include "../../include/ppgs_amd.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // one 16-byte MFMA operand fragment
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
@@ -49,11 +50,30 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
+// max(x, 0) on two packed 16-bit floats (bf16 or fp16) in ONE VALU instruction
+// (v_pk_max_i16): the sign bit makes every negative value, -0 included, a
+// negative integer; NaNs with the sign bit clear pass through like fmaxf's.
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ uint32_t relu_packed16(uint32_t packed) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, packed), s16x2{0, 0}));
+}
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+// two fp32 -> packed fp16 (round to nearest even): one v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+
+// kIsBF16 reads "16-bit operands" (bf16 or fp16): it selects the layouts and
+// epilogues both share; pack2 / cvt1 are the only places the formats differ.
 struct PrecBF16 {
     typedef uint16_t elem;
     static constexpr int kBytes = 2;
     static constexpr int KG = 32;   // elements per 64-byte K-group
     static constexpr bool kIsBF16 = true;
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ uint16_t cvt1(float v) { return f32_to_bf16_rne(v); }
     static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
             __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
@@ -63,6 +83,43 @@ struct PrecBF16 {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
             __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
+    // ... or C = another register quad (a bias: D and C are separate MFMA operands)
+    static __device__ __forceinline__ void mmac(f32x4& acc, const u32x4& a, const u32x4& b, const f32x4& c) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    // ReLU on two packed bf16: as signed 16-bit integers every negative value (and -0) is < 0
+    static __device__ __forceinline__ uint32_t relu2(uint32_t packed) { return relu_packed16(packed); }
+    // 32x32x16: A = 32 rows x 16 k (lane: row l & 31, k 8 (l >> 5) ..+7), B likewise with columns,
+    // C[row = 8 (i >> 2) + 4 (l >> 5) + (i & 3)][col = l & 31], i = 0..15
+    static __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+struct PrecF16 {
+    typedef uint16_t elem;
+    static constexpr int kBytes = 2;
+    static constexpr int KG = 32;
+    static constexpr bool kIsBF16 = true;
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ uint16_t cvt1(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
+    static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            __builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma0(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            __builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mmac(f32x4& acc, const u32x4& a, const u32x4& b, const f32x4& c) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            __builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t relu2(uint32_t packed) { return relu_packed16(packed); }
+    static __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
 };
 
 struct PrecF32 {
@@ -70,6 +127,8 @@ struct PrecF32 {
     static constexpr int kBytes = 4;
     static constexpr int KG = 16;
     static constexpr bool kIsBF16 = false;
+    static __device__ __forceinline__ uint32_t pack2(float, float) { return 0u; }   // never used: 32-bit layouts
+    static __device__ __forceinline__ float cvt1(float v) { return v; }
     static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
@@ -82,13 +141,20 @@ struct PrecF32 {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ void mmac(f32x4& acc, const u32x4& a, const u32x4& b, const f32x4& c) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t relu2(uint32_t packed) { return packed; }   // never used: 32-bit layouts
 };
 
 // Store 4 consecutive elements (fp32 values) as P::elem at dst (8/16 B aligned)
 template <class P>
 __device__ __forceinline__ void store4(void* dst, float a, float b, float c, float d) {
     if constexpr (P::kIsBF16) {
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(P::pack2(a, b), P::pack2(c, d));
     } else {
         *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
     }
@@ -116,8 +182,8 @@ struct PairStore {
     uint32_t lo0, lo1;
     __device__ __forceinline__ void put(void* dst8, int e, float a, float b, float c, float d) {
         if constexpr (P::kIsBF16) {
-            if (e == 0) { lo0 = pack_bf16x2(a, b); lo1 = pack_bf16x2(c, d); }
-            else *reinterpret_cast<u32x4*>(dst8) = u32x4{lo0, lo1, pack_bf16x2(a, b), pack_bf16x2(c, d)};
+            if (e == 0) { lo0 = P::pack2(a, b); lo1 = P::pack2(c, d); }
+            else *reinterpret_cast<u32x4*>(dst8) = u32x4{lo0, lo1, P::pack2(a, b), P::pack2(c, d)};
         } else {
             reinterpret_cast<float4*>(dst8)[e] = make_float4(a, b, c, d);
         }
@@ -188,6 +254,7 @@ struct LinearArgs {
     const PpgWindow* win;
     int M;                    // rows in the token-major buffers (multiple of 16)
     unsigned long long* dbg;  // PPG_LIN_TIMING builds: 16 s_memtime stamps per workgroup (tools/lin_timing.py)
+    int x_tiled;              // EPI_INCONV: X is written in X32 order (the layer32 kernel follows)
 };
 
 struct FfnArgs {
@@ -221,6 +288,49 @@ struct FfnArgs {
     int splits;
 };
 
+// Memory laid out for the feature-split layer kernel (160-token workgroup tiles):
+//  * X32: the fp32 residual stream in the kernel's accumulator order -- the float4 (token m,
+//    features n..n+3) sits where lane (token, feature half) of wave n/64 loads/stores it, so every
+//    residual load and every LayerNorm store is one contiguous KiB per wave instruction;
+//  * AO32: the attention output as the kernel's B fragments (token panel: [tile][5 token blocks]
+//    [16 K-steps] fragments of 1 KiB, slot 8 (l >> 5) + j of K-step ks = feature 16 ks + 8 (l >> 5) + j).
+__host__ __device__ inline size_t x32_index(int m, int n) {        // float index of X[m][n], n % 4 == 0
+    const int tile = m / 160, r = m - tile * 160, tb = r >> 5, tok = r & 31;
+    const int w = n >> 6, rb = (n >> 5) & 1, hh = (n >> 4) & 1, q = (n >> 2) & 3;
+    return ((((((size_t)tile * 4 + w) * 5 + tb) * 2 + rb) * 4 + q) * 64 + hh * 32 + tok) * 4 + (n & 3);
+}
+__host__ __device__ inline size_t ao32_byte(int m, int n) {        // byte offset of AO[m][n], n % 8 == 0, 16-bit elements
+    const int tile = m / 160, r = m - tile * 160, tb = r >> 5, tok = r & 31;
+    return ((((size_t)tile * 5 + tb) * 16 + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + tok) * 16;
+}
+
+// The feature-split layer kernel (ppg_layer32.hip): out-projection + residual + LayerNorm-1,
+// FFN + residual + LayerNorm-2 [, the next layer's Q/K/V projection] for 160-token workgroups
+// on v_mfma_f32_32x32x16.  Weights come as host-packed fragment images (1 KiB per MFMA A
+// fragment, in consumption order; ppg_engine.hip pack_layer32).
+struct Layer32Args {
+    const char* ao;           // attention output in AO32 order (see ao32_byte)
+    const char* wo_img;       // [4 waves][2 row blocks][16 k-steps] fragments
+    const char* w1_img;       // [F/128 chunks][4 waves][16 k-steps] fragments
+    const char* w2_img;       // [F/128 chunks][4 waves][2 row blocks][8 k-steps] fragments
+    const float* bo; const float* g1; const float* e1;      // out-proj bias, norm1
+    const float* b1; const float* b2; const float* g2; const float* e2;
+    float* X;                 // residual stream fp32 in X32 order (see x32_index), in/out
+    char* Xb;                 // row-major 16-bit copy of the result (operand of the kernels that follow); null: not written
+    int M;
+    int F;
+    // fused Q/K/V projection of the next layer (wq_img != null)
+    const char* wq_img;       // [4 waves][6 row blocks][16 k-steps] fragments
+    const float* bq;
+    char* qk_out;             // [M][2H] (q | k)
+    char* vt_out;             // transposed V [H][vt_ld]
+    int vt_ld;
+    const int* blk_win;
+    const PpgWindow* win;
+    unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
+    int debug_mode;           // PPGS_AMD_L32_DEBUG (bisecting): bit 0 skip the out-projection, bit 1 skip the FFN
+};
+
 // One attention workgroup's work: a query tile of one window.  The window fields
 // the kernel needs ride along (one 32-byte load instead of item -> window, two
 // dependent round trips at the head of every workgroup).
@@ -247,6 +357,7 @@ struct AttnArgs {
     const AttnItem* items;
     const PpgWindow* win;
     int M;
+    int ao_tiled;             // the output goes out in AO32 order (the layer32 kernel follows)
 };
 
 struct GatherArgs {

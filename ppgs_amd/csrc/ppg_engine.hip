@@ -46,6 +46,11 @@ uint16_t host_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// fp32 -> IEEE half, round to nearest even (subnormals and overflow to inf included)
+uint16_t host_f16(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
 // ----------------------------------------------------------------------------
 // Chunk planner (reference ppgs/model/transformer.py:49-64)
 // ----------------------------------------------------------------------------
@@ -182,6 +187,8 @@ struct DevLayer {
     char* wqkvk;          // W_qkv for the Q/K/V tail of the previous layer's FFN kernel: fp32 columns in paired order (= wqkv in bf16 mode)
     char* w1k;            // W1 for the out-proj-fused FFN: fp32 columns in paired order (= w1 in bf16 mode)
     float *g1, *e1, *g2, *e2;
+    // fragment images of the feature-split layer kernel (ppg_layer32.hip), 16-bit modes with hidden 256
+    char* wo_img = nullptr; char* w1_img = nullptr; char* w2_img = nullptr; char* wq_img = nullptr;
 };
 
 struct DevPlan {
@@ -217,6 +224,7 @@ struct PpgEngine {
     int ffn_split_max = 0;   // PPGS_AMD_FFN_SPLIT_MAX: cap on the hidden splits (0: half the chunks)
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
+    bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
                             // but kernels of the two halves then overlap and per-kernel timings blur)
@@ -323,7 +331,7 @@ int upload_matrix(PpgEngine* e, int rows, int cols, int rows_pad, int cols_pad, 
     if (e->sz == 2) {
         std::vector<uint16_t> tmp(n, 0);
         for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < cols; ++c) tmp[(size_t)r * cols_pad + c] = host_bf16(get(r, c));
+            for (int c = 0; c < cols; ++c) tmp[(size_t)r * cols_pad + c] = e->cfg.precision == PPG_PRECISION_FP16 ? host_f16(get(r, c)) : host_bf16(get(r, c));
         return upload(e, tmp.data(), n * 2, reinterpret_cast<void**>(dst));
     }
     std::vector<float> tmp(n, 0.f);
@@ -356,7 +364,7 @@ int choose_nt(const PpgEngine* e, int M, int max_nt) {
 // A workgroup streams all of W1/W2 through its CU whatever its tile size, so
 // few large tiles x several hidden splits beats many small tiles.
 void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) {
-    const int max_nt = (e->cfg.precision == PPG_PRECISION_BF16 && e->cfg.hidden_channels == 256) ? 3
+    const int max_nt = (e->sz == 2 && e->cfg.hidden_channels == 256) ? 3
                        : (e->cfg.hidden_channels == 256 ? 2 : 1);
     int nt = choose_nt(e, M, max_nt);
     int splits = 1;
@@ -376,7 +384,7 @@ void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) 
     // MFMA work per wave and chunk instead of nt; worth it when it saves a round or
     // shortens the one round there is (C2: 256 workgroups on 256 CUs instead of 214 larger ones)
     if (splits == 1 && e->ffn_mixed && e->ffn_fused && e->op_fused && e->ffn_nt == 0 &&
-        e->cfg.precision == PPG_PRECISION_BF16 && e->cfg.hidden_channels == 256) {
+        e->sz == 2 && e->cfg.hidden_channels == 256) {
         const int blocks_nt = (M + 64 * nt - 1) / (64 * nt), blocks_mixed = (M + 159) / 160;
         const double rounds_nt = (blocks_nt + e->num_cus - 1) / e->num_cus;
         const double rounds_mixed = (blocks_mixed + e->num_cus - 1) / e->num_cus;
@@ -395,11 +403,12 @@ Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
     w.qk_rows = (int)M + 64;
     w.vt_ld = vt_tokens + 64;
     w.xw = take(M * e->Cp * e->sz);
-    w.x = take(M * H * 4);
+    const size_t Mt = (M + 159) / 160 * 160;            // whole 160-token tiles (X32 / AO32 layouts of the layer32 kernel)
+    w.x = take(Mt * H * 4);
     w.xb = take(e->sz == 2 ? M * H * 2 : 0);
     w.qk = take((size_t)w.qk_rows * 2 * H * e->sz);
     w.vt = take((size_t)H * w.vt_ld * e->sz);
-    w.ao = take(M * H * e->sz);
+    w.ao = take(Mt * H * e->sz);
     w.hid = take(e->ffn_fused ? 0 : M * e->cfg.ffn_channels * e->sz);
     choose_ffn_tiling(e, tokens, &w.ffn_nt, &w.ffn_splits);
     w.part = take(w.ffn_splits > 1 ? (size_t)w.ffn_splits * M * H * 4 : 0);
@@ -650,7 +659,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (C < 1) return fail(PPG_EINVAL, "input_channels %d", C);
     if (cfg->chunk_length <= 2 * cfg->chunk_overlap || cfg->chunk_length > 512)
         return fail(PPG_EINVAL, "chunk_length %d / overlap %d unsupported", cfg->chunk_length, cfg->chunk_overlap);
-    if (cfg->precision != PPG_PRECISION_FP32 && cfg->precision != PPG_PRECISION_BF16)
+    if (cfg->precision != PPG_PRECISION_FP32 && cfg->precision != PPG_PRECISION_BF16 && cfg->precision != PPG_PRECISION_FP16)
         return fail(PPG_EINVAL, "precision %d", cfg->precision);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -661,7 +670,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     std::unique_ptr<PpgEngine> e(new PpgEngine());
     e->cfg = *cfg;
     e->device = device;
-    e->sz = cfg->precision == PPG_PRECISION_BF16 ? 2 : 4;
+    e->sz = cfg->precision == PPG_PRECISION_FP32 ? 4 : 2;
     e->KG = 64 / e->sz;
     e->head_dim = dh;
     e->Cp = round_up(C, e->KG);
@@ -687,6 +696,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_FFN_MIXED")) e->ffn_mixed = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_FFN_SPLIT_MAX")) e->ffn_split_max = atoi(v);
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
+    if (e->sz != 2 || H != 256 || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->lin_dbg), 16 * 8192 * 8));
@@ -767,6 +778,48 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
                                    return w[(size_t)r * F + grp * 32 + 16 * ee + 4 * g + rr];
                                },
                                &d.w2p);
+            if (rc) return rc;
+        }
+        if (e->layer32) {
+            // Fragment images (ppg_layer32.hip): fragment = 64 lanes x 8 elements, lane l = (row l & 31 of
+            // the 32-row block, K slots 8 (l >> 5) .. +7 of the 16-wide K-step).  Output rows of a
+            // block sit in the order phi the accumulator layout hands a lane 16 consecutive features
+            // in; where a GEMM's K is the previous accumulator (x1, h, x2) the K order follows it.
+            auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+            auto image = [&](int frags, auto get, char** dst) {          // get(frag, lane, j)
+                return upload_matrix(E, frags * 64, 8, frags * 64, 8,
+                                     [&](int r, int j) { return get(r >> 6, r & 63, j); }, dst);
+            };
+            const float* wo = wts->out_proj_weight[l];
+            rc = image(4 * 2 * 16, [&](int f, int ln, int j) {
+                const int ks = f & 15, rb = (f >> 4) & 1, w = f >> 5;
+                return wo[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * H + 16 * ks + 8 * (ln >> 5) + j];
+            }, &d.wo_img);
+            if (rc) return rc;
+            const float* w1 = wts->linear1_weight[l];
+            rc = image(F / 128 * 4 * 16, [&](int f, int ln, int j) {
+                const int ks = f & 15, w = (f >> 4) & 3, ch = f >> 6;
+                return w1[(size_t)(ch * 128 + 32 * w + (ln & 31)) * H + 32 * (ks >> 1) + 16 * (ln >> 5) + 8 * (ks & 1) + j];
+            }, &d.w1_img);
+            if (rc) return rc;
+            const float* w2 = wts->linear2_weight[l];
+            rc = image(F / 128 * 4 * 2 * 8, [&](int f, int ln, int j) {
+                const int ks = f & 7, rb = (f >> 3) & 1, w = (f >> 4) & 3, ch = f >> 6;
+                return w2[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * F + ch * 128 + 32 * (ks >> 1) + 16 * (ks & 1) +
+                          8 * (j >> 2) + 4 * (ln >> 5) + (j & 3)];
+            }, &d.w2_img);
+            if (rc) return rc;
+            // W_qkv of THIS layer (the previous layer's kernel runs it as its tail): per wave 6 steps of
+            // 32 rows: Q rows 64w + 32 rb + phi, K likewise, V rows in attn_kernel's tile order
+            // (V^T row r = natural feature pair_row(r)); K order = the x2 panel's (as W1)
+            const float* wq = wts->in_proj_weight[l];
+            rc = image(4 * 6 * 16, [&](int f, int ln, int j) {
+                const int ks = f & 15, st = (f >> 4) % 6, w = f / 96;
+                const int rb = st & 1, kind = st >> 1;
+                const int row = kind < 2 ? kind * H + 64 * w + 32 * rb + phi(ln & 31)
+                                         : 2 * H + pair_row(64 * w + 32 * rb + (ln & 31));
+                return wq[(size_t)row * H + 32 * (ks >> 1) + 16 * (ln >> 5) + 8 * (ks & 1) + j];
+            }, &d.wq_img);
             if (rc) return rc;
         }
         if ((rc = upload_f32(E, wts->in_proj_bias[l], 3 * H, 0, &d.bqkv))) return rc;
@@ -859,7 +912,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     char* hid = base + ws.hid;
     const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
 
-    const int nt = choose_nt(e, M, prec == PPG_PRECISION_BF16 ? 3 : 2);     // linear / conv kernels
+    const int nt = choose_nt(e, M, e->sz == 2 ? 3 : 2);     // linear / conv kernels
     // linear / conv kernels: measured best at C2 (two 256-register workgroups
     // per CU): 32-token waves for the wide projections, 16-token waves where
     // the epilogue dominates (LayerNorm, softmax scatter)
@@ -885,9 +938,11 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.X = X; a.Xb = Xb; a.v_start = INT_MAX; a.taps = 1;
         return a;
     };
+    const bool use32 = e->layer32 && e->ffn_fused && ws.ffn_splits == 1;
     {
         Timed t(e, PPG_K_INCONV, s);
         LinearArgs a = base_args();
+        a.x_tiled = use32;
         a.act = xw; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
         a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
         a.total_groups = e->in_total_groups;
@@ -915,9 +970,27 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
-            a.items = grp.d_items; a.win = grp.d_win; a.M = M;
+            a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32;
+            if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) if (atoi(v) & 8) a.ao_tiled = 0;
             a.dbg = l == 0 ? e->attn_dbg : nullptr;
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
+        }
+        if (use32) {
+            Timed t(e, PPG_K_FFN, s);
+            Layer32Args a{};
+            a.ao = ao; a.wo_img = d.wo_img; a.w1_img = d.w1_img; a.w2_img = d.w2_img;
+            a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2;
+            a.X = X; a.Xb = Xb; a.M = M; a.F = F; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
+            if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) a.debug_mode = atoi(v);
+            qkv_done = e->qkv_fused && l + 1 < c.num_layers;
+            if (qkv_done) {
+                const DevLayer& nx = e->layers[l + 1];
+                a.wq_img = nx.wq_img; a.bq = nx.bqkv; a.qk_out = qk; a.vt_out = vt; a.vt_ld = ws.vt_ld;
+                a.blk_win = grp.d_blk; a.win = grp.d_win;
+                a.Xb = nullptr;              // nobody reads the 16-bit copy: x2 goes straight into the tail
+            }
+            LAUNCH_OK(ppg::launch_layer32(prec, a, s), "layer32");
+            continue;
         }
         const bool fuse_op = e->ffn_fused && e->op_fused && ws.ffn_splits == 1;
         if (!fuse_op) {

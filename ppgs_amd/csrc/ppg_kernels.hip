@@ -381,8 +381,8 @@ __device__ __forceinline__ void ln_keep(
 #pragma unroll
         for (int kg = 0; kg < XG; ++kg) {
             if constexpr (P::kIsBF16) {
-                xf[kg][t] = u32x4{pack_bf16x2(v[2 * kg][0], v[2 * kg][1]), pack_bf16x2(v[2 * kg][2], v[2 * kg][3]),
-                                  pack_bf16x2(v[2 * kg + 1][0], v[2 * kg + 1][1]), pack_bf16x2(v[2 * kg + 1][2], v[2 * kg + 1][3])};
+                xf[kg][t] = u32x4{P::pack2(v[2 * kg][0], v[2 * kg][1]), P::pack2(v[2 * kg][2], v[2 * kg][3]),
+                                  P::pack2(v[2 * kg + 1][0], v[2 * kg + 1][1]), P::pack2(v[2 * kg + 1][2], v[2 * kg + 1][3])};
             } else {
                 xf[kg][t] = u32x4{__float_as_uint(v[kg][0]), __float_as_uint(v[kg][1]), __float_as_uint(v[kg][2]), __float_as_uint(v[kg][3])};
             }
@@ -422,9 +422,13 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
             int col, count;
             if (job < a.nwin) {
                 const PpgWindow w = a.win[job];
+                // a window with an odd number of 16-token blocks: its last 32-column group is only half
+                // written by the projections -- in the 16-bit modes the columns are permuted inside the
+                // group (position 8g + 4e + r), so the unwritten ones are NOT the linear tail: clear the
+                // whole group (this launch runs before the projections fill in their half)
                 const int r16 = (w.frames + 15) & ~15, r32 = (w.frames + 31) & ~31;
-                col = w.vt_off + r16;
-                count = r32 - r16;
+                col = w.vt_off + r32 - 32;
+                count = r32 != r16 ? 32 : 0;
             } else {
                 col = a.vt_tokens;
                 count = a.vt_ld - a.vt_tokens;
@@ -476,8 +480,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
             if (m < a.M && c0 + c < a.Cp) {
                 const float v = tile[c][tl];
                 typename P::elem* dst = reinterpret_cast<typename P::elem*>(a.xw) + (size_t)m * a.Cp + c0 + c;
-                if constexpr (P::kIsBF16) *dst = f32_to_bf16_rne(v);
-                else *dst = v;
+                *dst = P::cvt1(v);
             }
         }
     }
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 y.w = live[t] ? pv.w + (valid[t] ? acc[nb][t][3] + bv.w : 0.f) : 0.f;
                 if (inside[t]) {
                     const int m = tok0 + 16 * t + idx;
-                    *reinterpret_cast<float4*>(a.X + (size_t)m * a.H + n) = y;
+                    *reinterpret_cast<float4*>(a.X + (a.x_tiled ? x32_index(m, n) : (size_t)m * a.H + n)) = y;
                     if constexpr (P::kIsBF16) pair[t].put(a.Xb + ((size_t)m * a.H + (n & ~7)) * 2, nb & 1, y.x, y.y, y.z, y.w);
                 }
             }
@@ -719,8 +722,8 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                     char* dst = a.vt + ((size_t)(row - a.v_start) * a.vt_ld + vcol[t] + (P::kIsBF16 ? 8 : 4) * g) * P::kBytes;
                     if (paired) {
                         *reinterpret_cast<u32x4*>(dst) = u32x4{
-                            pack_bf16x2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), pack_bf16x2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
-                            pack_bf16x2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv), pack_bf16x2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv)};
+                            P::pack2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), P::pack2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
+                            P::pack2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv), P::pack2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv)};
                     } else {
                         store4<P>(dst, acc[nb][t][0] + bv, acc[nb][t][1] + bv, acc[nb][t][2] + bv, acc[nb][t][3] + bv);
                     }
@@ -941,26 +944,27 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
     // pack unit u = (hb, t): bias + ReLU on the phase-A accumulator, packed
     // straight into the phase-B B-fragment (see header comment)
     // (ROLE 1: the last owned block's accumulators come from the partner wave: hfar)
-    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NTA], f32x4 (&hfar)[HB], u32x4 (&b1f)[HB], u32x4 (&hf)[HG][NTB]) {
+    // (the bias is already in hv: it was the C operand of the block's first MFMA; in the
+    // 16-bit modes the ReLU runs on the packed pair, one v_pk_max_i16 per two values)
+    auto pack_unit = [&](auto uc, f32x4 (&hsrc)[HB][NTA], f32x4 (&hfar)[HB], u32x4 (&hf)[HG][NTB]) {
         constexpr int u = decltype(uc)::value;
         constexpr int hb = u / NTB, t = u % NTB;
-        const u32x4 bv = b1f[hb];
         const f32x4 hv = [&] { if constexpr (t < NTL) return hsrc[hb][t]; else return hfar[hb]; }();
-        const float h0 = fmaxf(hv[0] + __uint_as_float(bv.x), 0.f);
-        const float h1 = fmaxf(hv[1] + __uint_as_float(bv.y), 0.f);
-        const float h2 = fmaxf(hv[2] + __uint_as_float(bv.z), 0.f);
-        const float h3 = fmaxf(hv[3] + __uint_as_float(bv.w), 0.f);
         if constexpr (P::kIsBF16) {
-            if constexpr (hb & 1) { hf[hb >> 1][t].z = pack_bf16x2(h0, h1); hf[hb >> 1][t].w = pack_bf16x2(h2, h3); }
-            else                  { hf[hb >> 1][t].x = pack_bf16x2(h0, h1); hf[hb >> 1][t].y = pack_bf16x2(h2, h3); }
+            const uint32_t lo = P::relu2(P::pack2(hv[0], hv[1])), hi = P::relu2(P::pack2(hv[2], hv[3]));
+            if constexpr (hb & 1) { hf[hb >> 1][t].z = lo; hf[hb >> 1][t].w = hi; }
+            else                  { hf[hb >> 1][t].x = lo; hf[hb >> 1][t].y = hi; }
         } else {
-            hf[hb][t] = u32x4{__float_as_uint(h0), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+            hf[hb][t] = u32x4{__float_as_uint(fmaxf(hv[0], 0.f)), __float_as_uint(fmaxf(hv[1], 0.f)),
+                              __float_as_uint(fmaxf(hv[2], 0.f)), __float_as_uint(fmaxf(hv[3], 0.f))};
         }
     };
     // phase A of chunk c: h^T = W1c x^T (fragment i = (kg, hb)); the VALU of
     // `filler(step)` is issued between the MFMAs so the matrix pipe stays fed
     // (destination: rows OFF .. OFF + HB of `dst`, an [..][NT] accumulator array)
-    auto phase_a_into = [&](int c, auto& dst, auto off_tag, auto count_tag, auto filler) {
+    // `cinit`: null -> accumulate from zero; else cinit[hb] is the C operand of block hb's
+    // first MFMA (the lane's 4 bias values of the block's rows)
+    auto phase_a_into = [&](int c, auto& dst, auto off_tag, auto count_tag, auto cinit, auto filler) {
         constexpr int OFF = decltype(off_tag)::value;
         constexpr int COUNT = decltype(count_tag)::value;       // token blocks
         uint32_t fba[LA::VAR];
@@ -969,14 +973,25 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
             constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int t = 0; t < COUNT; ++t) {
-                if constexpr (i / HB == 0) P::mma0(dst[OFF + i % HB][t], wf, xf[0][t]);
-                else P::mma(dst[OFF + i % HB][t], wf, xf[i / HB][t]);
+                if constexpr (i / HB == 0) {
+                    if constexpr (std::is_same_v<decltype(cinit), std::nullptr_t>) P::mma0(dst[OFF + i % HB][t], wf, xf[0][t]);
+                    else P::mmac(dst[OFF + i % HB][t], wf, xf[0][t], cinit[i % HB]);
+                } else P::mma(dst[OFF + i % HB][t], wf, xf[i / HB][t]);
             }
             filler(ic);
         });
     };
-    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NTA], auto filler) {
-        phase_a_into(c, hdst, std::integral_constant<int, 0>{}, std::integral_constant<int, NTA>{}, filler);
+    auto phase_a = [&](int c, f32x4 (&hdst)[HB][NTA], const f32x4 (&bias)[HB], auto filler) {
+        phase_a_into(c, hdst, std::integral_constant<int, 0>{}, std::integral_constant<int, NTA>{}, &bias[0], filler);
+    };
+    // b1 of hidden chunk c as the lane's C operands (rows 4g .. 4g+3 of each 16-row block)
+    auto load_b1 = [&](int c, f32x4 (&bias)[HB]) {
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            u32x4 raw;
+            ds_read_b128_asm<0>(raw, lds_addr(ldsb1) + (hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
+            bias[hb] = __builtin_bit_cast(f32x4, raw);
+        }
     };
 
 #ifdef PPG_FFN_TIMING
@@ -1001,7 +1016,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
                 dma_wait_barrier();
                 pstamp(1 + 2 * I);
                 if constexpr (I == OT - 1) load_residual_rows<NBH>(res0, a.X, H, tok0 + idx, a.M, g);
-                phase_a_into(I, yacc, std::integral_constant<int, I * HB>{}, std::integral_constant<int, NTB>{}, [](auto) {});
+                phase_a_into(I, yacc, std::integral_constant<int, I * HB>{}, std::integral_constant<int, NTB>{}, nullptr, [](auto) {});
                 __syncthreads();              // buffer I & 1 is free for the tile after next
                 if constexpr (I + 2 < OT) stage_wo(I + 2);
                 else if (I + 2 - OT < NC) stage_w1(I + 2 - OT);
@@ -1038,10 +1053,8 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
     };
     auto chunk = [&](int c, f32x4 (&hcur)[HB][NTA], f32x4 (&hnext)[HB][NTA]) {
         stamp(c, 0);
-        u32x4 b1f[HB];
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
-            ds_read_b128_asm<0>(b1f[hb], lds_addr(ldsb1) + (hidden_chunk(c) * HC + hb * 16 + 4 * g) * 4);
+        f32x4 b1n[HB];                       // bias of the NEXT chunk: C operands of its phase A
+        if (c + 1 < NC) load_b1(c + 1, b1n);
         u32x4 hf[HG][NTB];
         f32x4 hfar[HB];
         if constexpr (ROLE == 1) {
@@ -1057,32 +1070,26 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         if (c + 1 < NC) stage_w2(c + 1);
         stamp(c, 1);
         if (c + 1 < NC) {
-            phase_a(c + 1, hnext, [&](auto ic) {
+            // (stream step 0 waits on an LDS op younger than the b1 / hand-off reads above)
+            phase_a(c + 1, hnext, b1n, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i == 0) {
-                    // stream step 0 waited on an LDS op younger than the b1 reads
+                if constexpr (i == 0 && ROLE == 1) {
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
-                    if constexpr (ROLE == 1) {
-#pragma unroll
-                        for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(hfar[hb]));
-                    }
+                    for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(hfar[hb]));
                 }
                 // spread the UNITS pack units evenly over the RA stream steps
                 if constexpr ((i * UNITS) / RA != ((i + 1) * UNITS) / RA)
-                    pack_unit(std::integral_constant<int, (i * UNITS) / RA>{}, hcur, hfar, b1f, hf);
+                    pack_unit(std::integral_constant<int, (i * UNITS) / RA>{}, hcur, hfar, hf);
             });
             if constexpr (ROLE == 2) send_foreign(c + 1, hnext);
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(b1f[hb]));
             if constexpr (ROLE == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) asm volatile("" : "+v"(hfar[hb]));
             }
             [&]<int... U>(std::integer_sequence<int, U...>) {
-                (pack_unit(std::integral_constant<int, U>{}, hcur, hfar, b1f, hf), ...);
+                (pack_unit(std::integral_constant<int, U>{}, hcur, hfar, hf), ...);
             }(std::make_integer_sequence<int, UNITS>{});
         }
         stamp(c, 2);
@@ -1113,7 +1120,11 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
 #pragma unroll
         for (int kg = 0; kg < XG; ++kg) asm volatile("" : "+v"(xf[kg][NTA - 1]));
     }
-    phase_a(0, h0, [](auto) {});
+    {
+        f32x4 b10[HB];
+        load_b1(0, b10);
+        phase_a(0, h0, b10, [](auto) {});
+    }
     if constexpr (ROLE == 2) send_foreign(0, h0);
     __syncthreads();                      // W1 buffer 0 is re-filled by chunk 0's DMA; hand-off 0 is written
     for (int c = 0; c < NC; ++c) {
@@ -1124,6 +1135,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
             for (int t = 0; t < NTA; ++t) h0[hb][t] = h1[hb][t];
     }
 
+    pstamp(9);
     if (a.partial != nullptr) {
         // split-hidden: raw partial sums, [split][token][feature] fp32
         float* part = a.partial + (size_t)blockIdx.y * a.M * H;
@@ -1172,13 +1184,14 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         // the chunk loop ended on a barrier: all four buffers are free
         stage_q(0); stage_q(1); stage_q(2);
         resln<P, NBH, NT, LN_NO_RESIDUAL_KEEP>(yacc, lnp2, a.X, nullptr, H, tok0e, a.M, idxe, ge);
+        pstamp(10);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int kg = 0; kg < XG; ++kg) {
                 if constexpr (P::kIsBF16) {
-                    xf[kg][t] = u32x4{pack_bf16x2(yacc[2 * kg][t][0], yacc[2 * kg][t][1]), pack_bf16x2(yacc[2 * kg][t][2], yacc[2 * kg][t][3]),
-                                      pack_bf16x2(yacc[2 * kg + 1][t][0], yacc[2 * kg + 1][t][1]), pack_bf16x2(yacc[2 * kg + 1][t][2], yacc[2 * kg + 1][t][3])};
+                    xf[kg][t] = u32x4{P::pack2(yacc[2 * kg][t][0], yacc[2 * kg][t][1]), P::pack2(yacc[2 * kg][t][2], yacc[2 * kg][t][3]),
+                                      P::pack2(yacc[2 * kg + 1][t][0], yacc[2 * kg + 1][t][1]), P::pack2(yacc[2 * kg + 1][t][2], yacc[2 * kg + 1][t][3])};
                 } else {
                     xf[kg][t] = u32x4{__float_as_uint(yacc[kg][t][0]), __float_as_uint(yacc[kg][t][1]),
                                       __float_as_uint(yacc[kg][t][2]), __float_as_uint(yacc[kg][t][3])};
@@ -1270,8 +1283,8 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
                         char* dst = a.vt_out + ((size_t)(row - v_start) * a.vt_ld + vcol[t] + (P::kIsBF16 ? 8 : 4) * g) * P::kBytes;
                         if (paired) {
                             *reinterpret_cast<u32x4*>(dst) = u32x4{
-                                pack_bf16x2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), pack_bf16x2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
-                                pack_bf16x2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv), pack_bf16x2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv)};
+                                P::pack2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), P::pack2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
+                                P::pack2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv), P::pack2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv)};
                         } else {
                             store4<P>(dst, acc[nb][t][0] + bv, acc[nb][t][1] + bv, acc[nb][t][2] + bv, acc[nb][t][3] + bv);
                         }
@@ -1283,6 +1296,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
             if (i + 3 < QT) stage_q(i + 3);       // into the buffer tile i-1 was read from (all waves passed this iteration's barrier)
             qstamp(i, 5);
         }
+        pstamp(11);
     }
 }
 
@@ -1514,8 +1528,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
             const float p3 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][3], c, -mc[t]));
             psum[t] += (p0 + p1) + (p2 + p3);
             if constexpr (P::kIsBF16) {
-                if constexpr (kb & 1) { pf[kb >> 1][t].z = pack_bf16x2(p0, p1); pf[kb >> 1][t].w = pack_bf16x2(p2, p3); }
-                else                  { pf[kb >> 1][t].x = pack_bf16x2(p0, p1); pf[kb >> 1][t].y = pack_bf16x2(p2, p3); }
+                if constexpr (kb & 1) { pf[kb >> 1][t].z = P::pack2(p0, p1); pf[kb >> 1][t].w = P::pack2(p2, p3); }
+                else                  { pf[kb >> 1][t].x = P::pack2(p0, p1); pf[kb >> 1][t].y = P::pack2(p2, p3); }
             } else {
                 pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
             }
@@ -1594,7 +1608,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const int n = head * DH + pair_feature(db, g);
-            pair.put(a.ao + ((size_t)m * a.H + (n & ~7)) * P::kBytes, db & 1,
+            pair.put(a.ao + ((a.ao_tiled && P::kIsBF16) ? ao32_byte(m, n & ~7) : ((size_t)m * a.H + (n & ~7)) * P::kBytes), db & 1,
                      oacc[db][t][0] * inv, oacc[db][t][1] * inv,
                      oacc[db][t][2] * inv, oacc[db][t][3] * inv);
         }
@@ -1712,10 +1726,22 @@ namespace ppg {
 
 int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }
 
+// -DPPG_ONLY_BF16: kernel experiments build only the bf16 instantiations (a third of the compile time)
+#ifdef PPG_ONLY_BF16
+#define PPG_OTHER_PRECISIONS 0
+#else
+#define PPG_OTHER_PRECISIONS 1
+#endif
+
 hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s) {
     dim3 grid((a.M + 63) / 64, (a.Cp + 31) / 32 + 1);       // + the housekeeping row
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(gather_kernel<PrecBF16>, grid, dim3(256), 0, s, a);
+#if PPG_OTHER_PRECISIONS
+    else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(gather_kernel<PrecF16>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gather_kernel<PrecF32>, grid, dim3(256), 0, s, a);
+#else
+    else return hipErrorInvalidValue;
+#endif
     return hipGetLastError();
 }
 
@@ -1727,17 +1753,32 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
 
 hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s) {
     if (precision == PPG_PRECISION_BF16) return launch_linear_p<PrecBF16>(epi, nb, nt, a, ypasses, s);
+#if PPG_OTHER_PRECISIONS
+    if (precision == PPG_PRECISION_FP16) return launch_linear_p<PrecF16>(epi, nb, nt, a, ypasses, s);
     return launch_linear_p<PrecF32>(epi, nb, nt, a, ypasses, s);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s) {
     if (precision == PPG_PRECISION_BF16) return launch_ffn_p<PrecBF16>(a, nt, s);
+#if PPG_OTHER_PRECISIONS
+    if (precision == PPG_PRECISION_FP16) return launch_ffn_p<PrecF16>(a, nt, s);
     return launch_ffn_p<PrecF32>(a, nt, s);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
     if (precision == PPG_PRECISION_BF16) return launch_attn_p<PrecBF16>(a, nitems, heads, head_dim, s);
+#if PPG_OTHER_PRECISIONS
+    if (precision == PPG_PRECISION_FP16) return launch_attn_p<PrecF16>(a, nitems, heads, head_dim, s);
     return launch_attn_p<PrecF32>(a, nitems, heads, head_dim, s);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace ppg

@@ -19,6 +19,9 @@ hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArg
 constexpr int kFfnMixedTiling = 5;
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
+// feature-split layer kernel (ppg_layer32.hip): 16-bit precisions, hidden 256, F a multiple of 128
+hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s);
+constexpr int kLayer32Tokens = 160;   // token rows per workgroup
 
 constexpr int kMaxMelWeights = 1536;   // LDS room for the packed filterbank (1001 non-zeros + interior zeros)
 

@@ -1,0 +1,518 @@
+// The feature-split layer kernel for gfx950: everything between two attention
+// kernels of one encoder layer (reference: torch TransformerEncoderLayer._sa_block's
+// out_proj, norm1, _ff_block, norm2 -- SURVEY.md 2.3 rows M5/M6 -- and the next
+// layer's in_proj) for a 160-token workgroup, on v_mfma_f32_32x32x16.
+//
+// Why this shape (measured, tools/dma_probe.hip + tools/ffn32_probe.hip):
+//  * one wave issues v_mfma_f32_16x16x32_bf16 every ~21.6 cycles but
+//    v_mfma_f32_32x32x16_bf16 every 32: the same FLOPs in 74 % of the cycles;
+//  * a 1 KiB global_load_lds costs the issuing wave ~60 cycles during which its SIMD's
+//    matrix pipe idles (one 512-register wave per SIMD), 21 % of the token-split
+//    kernel's chunk loop -- a plain global_load_dwordx4 into registers between two
+//    32x32 MFMAs costs next to nothing.
+// So the operands trade places against ffn_body (ppg_kernels.hip): the four waves
+// (one per SIMD) all work on ALL 160 tokens -- 5 blocks of 32, the MFMA's N -- and
+// split the FEATURES: wave w owns output features 64w..64w+63 of every 256-wide
+// result and hidden rows 32w..32w+31 of every 128-hidden chunk.  Weights never touch
+// LDS: a wave loads only its own rows, as ready-made A fragments the host packed in
+// consumption order (1 KiB = one coalesced global_load_dwordx4 per fragment).
+// Activations are the B operands and live in LDS as fragments too (lane-linear, no
+// swizzle needed): the 80 KiB token panel (attention output, then x1, then x2) and
+// the chunk's 40 KiB of h.  The work is balanced by construction (no 3/3/2/2 roles),
+// LayerNorm statistics cross the waves through 5 KiB of LDS.
+//
+// Accumulator layout (32x32 C): lane l holds token l & 31; register i = 4q + r of row
+// block rb is tile row 8q + 4(l >> 5) + r, which the host maps to natural feature
+//   64 w + 32 rb + 16 (l >> 5) + 4 q + r           ("phi": 16 consecutive features per lane)
+// so a lane's 16 values of a block are 64 contiguous bytes of an fp32 row.  Packed to
+// 16 bits, registers (q = 2s, 2s+1) are exactly the B fragment of K-step s: the
+// accumulator of one GEMM is the operand of the next after ONE ds_write_b128.
+#include "ppg_device.h"
+#include "ppg_launch.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+constexpr float kLnEps32 = 1e-5f;
+constexpr int TB = 5;                 // token blocks of 32 per workgroup
+constexpr int HID = 256;              // hidden width (4 waves x 2 row blocks x 32)
+constexpr int HC = 128;               // hidden rows of the FFN per chunk (4 waves x 32)
+
+// LDS map (bytes)
+constexpr int L_ACT = 0;              // token panel: fragments [tb][16 k-steps] of 1 KiB
+constexpr int L_H = 81920;            // h of one chunk: fragments [tb][8 k-steps]
+constexpr int L_LNP1 = 122880;        // [bo | gamma1 | beta1]
+constexpr int L_LNP2 = 125952;        // [b2 | gamma2 | beta2]
+constexpr int L_BQ = 129024;          // next layer's in_proj bias (3 x 256)
+constexpr int L_STATS = 132096;       // LayerNorm partial sums: [2 rounds][4 waves][160]
+constexpr int L_B1 = 137216;          // b1, F floats
+
+__device__ __forceinline__ uint32_t lds_addr32(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void ds_read128(u32x4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait32(u32x4& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// 1 KiB fragment -> registers: wave-uniform base in SGPRs + lane * 16 + immediate
+template <int OFF>
+__device__ __forceinline__ void gload128(u32x4& dst, uint32_t voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+// fragment k of a run of fragments at `base` (the immediate reaches 4 KiB)
+template <int K>
+__device__ __forceinline__ void gload_frag(u32x4& dst, uint32_t voff, const char* base) {
+    gload128<(K % 4) * 1024>(dst, voff, base + (K / 4) * 4096);
+}
+// every load issued so far has landed; the registers are tied so no use moves above
+template <int COUNT>
+__device__ __forceinline__ void vm_wait_all(u32x4 (&r)[COUNT]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < COUNT; ++i) asm volatile("" : "+v"(r[i]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+// 16-byte global -> LDS DMA, per-lane source offset (the attention output's rows)
+__device__ __forceinline__ void glds16(const char* uniform_base, uint32_t lane_off, uint32_t lds_wave_addr) {
+    const uint64_t b = reinterpret_cast<uint64_t>(uniform_base);
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave_addr)) : "memory", "m0");
+}
+
+// Stream of N LDS fragments, D reads in flight; fragment of step i at byte offset
+// OFFS::at(i) from b0 (b1 = b0 + 64 KiB covers the offsets the 16-bit field cannot)
+template <class OFFS, int I, int N, int D, class USE>
+__device__ __forceinline__ void stream_step(u32x4 (&ring)[D], uint32_t b0, uint32_t b1, USE& use) {
+    if constexpr (I < N) {
+        lgkm_wait32<(N - 1 - I < D - 1) ? (N - 1 - I) : (D - 1)>(ring[I % D]);
+        use(std::integral_constant<int, I>{}, ring[I % D]);
+        if constexpr (I + D < N) {
+            constexpr int off = OFFS::at(I + D);
+            if constexpr (off < 65536) ds_read128<off>(ring[I % D], b0); else ds_read128<off - 65536>(ring[I % D], b1);
+        }
+        stream_step<OFFS, I + 1, N, D>(ring, b0, b1, use);
+    }
+}
+template <class OFFS, int I, int N, int D>
+__device__ __forceinline__ void stream_prime(u32x4 (&ring)[D], uint32_t b0, uint32_t b1) {
+    if constexpr (I < D && I < N) {
+        constexpr int off = OFFS::at(I);
+        if constexpr (off < 65536) ds_read128<off>(ring[I], b0); else ds_read128<off - 65536>(ring[I], b1);
+        stream_prime<OFFS, I + 1, N, D>(ring, b0, b1);
+    }
+}
+template <class OFFS, int N, int D, class USE>
+__device__ __forceinline__ void stream(uint32_t b0, uint32_t b1, USE use) {
+    u32x4 ring[D];
+    stream_prime<OFFS, 0, N, D>(ring, b0, b1);
+    stream_step<OFFS, 0, N, D>(ring, b0, b1, use);
+}
+// step i = ks * 5 + tb: panel fragment tb * 16 + ks (16 K-steps) / h fragment tb * 8 + ks (8 K-steps)
+struct OffPanel { static constexpr int at(int i) { return ((i % TB) * 16 + i / TB) * 1024; } };
+struct OffH { static constexpr int at(int i) { return ((i % TB) * 8 + i / TB) * 1024; } };
+
+__device__ __forceinline__ float pair_sum(float v) {          // lanes l and l + 32
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <class P, bool QKV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void layer32_kernel(Layer32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * (TB * 32);
+    const int NCH = a.F / HC;
+    const uint32_t lds0 = lds_addr32(smem);
+    const uint32_t voff = lane * 16;
+    const uint32_t pb0 = lds0 + L_ACT + lane * 16, pb1 = pb0 + 65536;   // panel fragments
+    const uint32_t hb0 = lds0 + L_H + lane * 16;                         // h fragments
+    float* lnp1 = reinterpret_cast<float*>(smem + L_LNP1);
+    float* lnp2 = reinterpret_cast<float*>(smem + L_LNP2);
+    float* stats = reinterpret_cast<float*>(smem + L_STATS);
+
+#ifdef PPG_FFN_TIMING
+    auto pstamp = [&](int k) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[128 + wave * 16 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto pstamp = [&](int) {};
+#endif
+    pstamp(0);
+
+    u32x4 w1f[16], w2f[16];
+    // ---- attention output (AO32 order: this tile's 80 fragments are one contiguous 80 KiB) -> LDS panel
+    if (a.debug_mode & 8) {          // bisecting: row-major attention output
+        uint32_t rowoff[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) rowoff[t] = (uint32_t)min(m0 + 32 * t + tok, a.M - 1) * (HID * 2) + hh * 16;
+#pragma unroll
+        for (int i = 0; i < TB * 16 / 4; ++i) {
+            const int p = 4 * i + wave;
+            const int t = p >> 4, ks = p & 15;
+            uint32_t ro = rowoff[0];
+#pragma unroll
+            for (int u = 1; u < TB; ++u) ro = (t == u) ? rowoff[u] : ro;
+            glds16(a.ao, ro + ks * 32, lds0 + L_ACT + p * 1024);
+        }
+    } else {
+        const char* tile = a.ao + (size_t)blockIdx.x * (TB * 16 * 1024);
+#pragma unroll
+        for (int i = 0; i < TB * 16 / 4; ++i) {
+            const int p = 4 * i + wave;
+            glds16(tile + (size_t)p * 1024, voff, lds0 + L_ACT + p * 1024);
+        }
+    }
+    f32x16 yacc[2][TB];
+    // parameters
+    for (int i = tid; i < a.F / 4; i += 256)
+        reinterpret_cast<float4*>(smem + L_B1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
+    for (int i = tid; i < 3 * HID / 4; i += 256) {
+        const int v = i / (HID / 4), j = i - v * (HID / 4);
+        reinterpret_cast<float4*>(lnp1)[i] = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
+        reinterpret_cast<float4*>(lnp2)[i] = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
+        if constexpr (QKV) reinterpret_cast<float4*>(smem + L_BQ)[i] = reinterpret_cast<const float4*>(a.bq)[i];
+    }
+    // ---- W_o fragments of this wave (2 row blocks x 16 K-steps) straight to registers.  Issued
+    // only now: registers written by an asm load must not be spilled before the data is in, and
+    // the compiler does not know they are in flight -- nothing register-hungry may sit between
+    // such a load and its wait.
+    {
+        const char* base = a.wo_img + (size_t)wave * 32768;
+        [&]<int... K>(std::integer_sequence<int, K...>) {
+            (gload_frag<K>(w1f[K], voff, base), ...);
+            (gload_frag<K>(w2f[K], voff, base + 16384), ...);
+        }(std::make_integer_sequence<int, 16>{});
+    }
+    vm_wait_all(w1f);
+    vm_wait_all(w2f);
+    __syncthreads();
+    pstamp(1);
+
+    // ---- out-projection: y[rb][tb] = W_o[rows of this wave] ao --------------------------------
+    if (!(a.debug_mode & 1)) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        stream<OffPanel, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int ks = i / TB, tb = i % TB;
+            if constexpr (ks == 0) {
+                yacc[0][tb] = P::mma32(w1f[0], bf, zero);
+                yacc[1][tb] = P::mma32(w2f[0], bf, zero);
+            } else {
+                yacc[0][tb] = P::mma32(w1f[ks], bf, yacc[0][tb]);
+                yacc[1][tb] = P::mma32(w2f[ks], bf, yacc[1][tb]);
+            }
+        });
+    }
+    pstamp(2);
+    // W1 fragments of chunk 0 travel while LayerNorm-1 runs
+    auto load_w1 = [&](int c) {
+        const char* base = a.w1_img + ((size_t)c * 4 + wave) * 16384;
+        [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(w1f[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
+    };
+
+    // ---- LayerNorm over the 256 features of a token, spread over the four waves ---------------
+    // acc <- LN(acc + bias [+ X]) * gamma + beta; `emit(tb, rb, y)` gets the 16 results of a block.
+    // One pass for the statistics (sum and sum of squares in fp32: the inputs are O(1) residual
+    // sums, var = E[v^2] - mean^2 loses nothing the 16-bit operands have not lost already), one
+    // exchange through LDS, gamma / beta of the lane's 32 features in registers for all 5 blocks.
+    float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * 2 * 4 * 256) + lane * 4;   // this lane's X32 slots
+    auto layer_norm = [&](auto residual_tag, const float* lnp, auto emit) {
+        constexpr bool RES = decltype(residual_tag)::value;
+        float4 bias4[2][4];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias4[rb][q] = *reinterpret_cast<const float4*>(lnp + 64 * wave + 32 * rb + 16 * hh + 4 * q);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            float sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 bv = bias4[rb][q];
+                    if constexpr (RES) {     // X32 order: one contiguous KiB per load instruction
+                        const float4 rv = *reinterpret_cast<const float4*>(xt + ((t * 2 + rb) * 4 + q) * 256);
+                        bv.x += rv.x; bv.y += rv.y; bv.z += rv.z; bv.w += rv.w;
+                    }
+                    yacc[rb][t][4 * q + 0] += bv.x; yacc[rb][t][4 * q + 1] += bv.y;
+                    yacc[rb][t][4 * q + 2] += bv.z; yacc[rb][t][4 * q + 3] += bv.w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = yacc[rb][t][4 * q + r];
+                        sum += v;
+                        sq = fmaf(v, v, sq);
+                    }
+                }
+            sum = pair_sum(sum);
+            sq = pair_sum(sq);
+            if (hh == 0) {
+                stats[wave * 160 + 32 * t + tok] = sum;
+                stats[640 + wave * 160 + 32 * t + tok] = sq;
+            }
+        }
+        float4 gv[2][4], ev[2][4];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 64 * wave + 32 * rb + 16 * hh + 4 * q;
+                gv[rb][q] = *reinterpret_cast<const float4*>(lnp + HID + n);
+                ev[rb][q] = *reinterpret_cast<const float4*>(lnp + 2 * HID + n);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const float* s = stats + 32 * t + tok;
+            const float mean = ((s[0] + s[160]) + (s[320] + s[480])) * (1.0f / HID);
+            const float ex2 = ((s[640] + s[800]) + (s[960] + s[1120])) * (1.0f / HID);
+            const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + kLnEps32);
+            const float shift = -mean * rstd;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    yacc[rb][t][4 * q + 0] = fmaf(fmaf(yacc[rb][t][4 * q + 0], rstd, shift), gv[rb][q].x, ev[rb][q].x);
+                    yacc[rb][t][4 * q + 1] = fmaf(fmaf(yacc[rb][t][4 * q + 1], rstd, shift), gv[rb][q].y, ev[rb][q].y);
+                    yacc[rb][t][4 * q + 2] = fmaf(fmaf(yacc[rb][t][4 * q + 2], rstd, shift), gv[rb][q].z, ev[rb][q].z);
+                    yacc[rb][t][4 * q + 3] = fmaf(fmaf(yacc[rb][t][4 * q + 3], rstd, shift), gv[rb][q].w, ev[rb][q].w);
+                }
+                emit(t, rb, yacc[rb][t]);
+            }
+        }
+    };
+    // the 16 results of block (tb, rb), packed: K-steps 4w + 2rb, 4w + 2rb + 1 of the token panel
+    // (slot 4e + r of K-step s' = register 4 (2s' + e) + r = natural feature 32 (ks/2) + 16 hh + 8 (ks%2) + 4e + r)
+    auto panel_write = [&](int t, int rb, const f32x16& y) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x4 frag = u32x4{P::pack2(y[8 * s + 0], y[8 * s + 1]), P::pack2(y[8 * s + 2], y[8 * s + 3]),
+                                     P::pack2(y[8 * s + 4], y[8 * s + 5]), P::pack2(y[8 * s + 6], y[8 * s + 7])};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(pb0 + (uint32_t)((t * 16 + 4 * wave + 2 * rb + s) * 1024)), "v"(frag) : "memory");
+        }
+    };
+    // LayerNorm-1: the panel holds x1 afterwards (every wave finished reading the attention
+    // output two barriers ago), the accumulators keep x1 as the FFN's residual
+    layer_norm(std::true_type{}, lnp1, panel_write);
+    load_w1(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    pstamp(3);
+
+    // ---- FFN: per 128-hidden chunk  h = relu(W1c x1 + b1c)  (phase A),  y += W2c h  (phase B) ---
+    for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
+        f32x16 bias;            // C operand of the chunk's first MFMAs: b1 of the lane's 16 hidden rows
+        {
+            u32x4 braw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ds_read128<0>(braw[q], lds0 + L_B1 + (uint32_t)((c * HC + 32 * wave + 8 * q + 4 * hh) * 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                asm volatile("" : "+v"(braw[q]));
+                bias[4 * q + 0] = __uint_as_float(braw[q].x); bias[4 * q + 1] = __uint_as_float(braw[q].y);
+                bias[4 * q + 2] = __uint_as_float(braw[q].z); bias[4 * q + 3] = __uint_as_float(braw[q].w);
+            }
+        }
+        vm_wait_all(w1f);
+        const char* w2base = a.w2_img + ((size_t)c * 4 + wave) * 16384;
+        f32x16 hacc[TB];
+        stream<OffPanel, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int ks = i / TB, tb = i % TB;
+            if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+            else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+            // this chunk's W2 fragments, one load per 5 MFMAs
+            if constexpr (tb == 2) gload_frag<ks>(w2f[ks], voff, w2base);
+        });
+        __syncthreads();                     // every wave is done reading the previous chunk's h
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4 frag = u32x4{P::relu2(P::pack2(hacc[t][8 * s + 0], hacc[t][8 * s + 1])), P::relu2(P::pack2(hacc[t][8 * s + 2], hacc[t][8 * s + 3])),
+                                         P::relu2(P::pack2(hacc[t][8 * s + 4], hacc[t][8 * s + 5])), P::relu2(P::pack2(hacc[t][8 * s + 6], hacc[t][8 * s + 7]))};
+                asm volatile("ds_write_b128 %0, %1" :: "v"(hb0 + (uint32_t)((t * 8 + 2 * wave + s) * 1024)), "v"(frag) : "memory");
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        vm_wait_all(w2f);
+        // next into the W1 registers: the next chunk's fragments; after the last chunk the first
+        // step of the Q/K/V tail (or, without a tail, the chunk's own fragments again: harmless)
+        const char* w1base = c + 1 < NCH ? a.w1_img + ((size_t)(c + 1) * 4 + wave) * 16384
+                             : (QKV ? a.wq_img + (size_t)wave * 6 * 16384 : a.w1_img + ((size_t)c * 4 + wave) * 16384);
+        stream<OffH, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int ks = i / TB, tb = i % TB;
+            yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
+            yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+            // the next chunk's W1 fragments, two loads per 10 MFMAs
+            if constexpr (tb == 1 || tb == 3) gload_frag<2 * ks + (tb == 3)>(w1f[2 * ks + (tb == 3)], voff, w1base);
+        });
+    }
+    vm_wait_all(w1f);
+    pstamp(4);
+
+    // ---- LayerNorm-2 -> X (fp32 residual stream, X32 order: one KiB per store) and its row-major 16-bit copy
+    layer_norm(std::false_type{}, lnp2, [&](int t, int rb, const f32x16& y) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(xt + ((t * 2 + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        if constexpr (QKV) panel_write(t, rb, y);          // x2: the B operand of the Q/K/V tail
+        const int m = m0 + 32 * t + tok;
+        if (a.Xb && m < a.M) {
+            char* brow = a.Xb + ((size_t)m * HID + 64 * wave + 32 * rb + 16 * hh) * 2;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                *reinterpret_cast<u32x4*>(brow + 16 * s) = u32x4{P::pack2(y[8 * s + 0], y[8 * s + 1]), P::pack2(y[8 * s + 2], y[8 * s + 3]),
+                                                                  P::pack2(y[8 * s + 4], y[8 * s + 5]), P::pack2(y[8 * s + 6], y[8 * s + 7])};
+        }
+    });
+    pstamp(5);
+
+    if constexpr (QKV) {
+        // ---- the next layer's Q/K/V projection on x2 ------------------------------------------
+        // Six steps of one 32-row block each: Q and K features 64w..64w+63 (row-major stores,
+        // a lane owns 16 consecutive features of its token) and V features 64w..64w+63 with the
+        // MFMA operands swapped, so that the accumulator comes out transposed for V^T (a lane owns
+        // one V^T row and 16 tokens).  W fragments alternate between the two 16-fragment register
+        // sets: the next step's travel under this step's MFMAs.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                       // x2 panel complete
+        const float* bq = reinterpret_cast<const float*>(smem + L_BQ);
+        // transposed-V columns of the wave-uniform 16-token halves of every token block
+        int vcol[TB][2];
+        bool valigned[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mb = m0 + 32 * t + 16 * h;
+                vcol[t][h] = -1;
+                if (mb < a.M) {
+                    const int w = a.blk_win[mb >> 4];
+                    if (w >= 0) {
+                        const int ttb = mb - a.win[w].tok_off;
+                        vcol[t][h] = a.win[w].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
+                    }
+                }
+            }
+            valigned[t] = vcol[t][0] >= 0 && vcol[t][1] == vcol[t][0] + 4 && (vcol[t][0] & 31) == 0;
+        }
+        // (step 0's fragments arrived with the last FFN chunk)
+        auto step = [&](auto step_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
+            constexpr int STEP = decltype(step_tag)::value;
+            constexpr bool SWAP = STEP >= 4;
+            const char* nbase = a.wq_img + (((size_t)wave * 6 + (STEP + 1 < 6 ? STEP + 1 : STEP)) * 16) * 1024;
+            f32x16 acc[TB];
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            stream<OffPanel, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                if constexpr (ks == 0) acc[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
+                else acc[tb] = SWAP ? P::mma32(bf, cur[ks], acc[tb]) : P::mma32(cur[ks], bf, acc[tb]);
+                // the next step's fragments: issued in the first 48 of the 80 stream steps so that ...
+                if constexpr (STEP + 1 < 6 && i % 3 == 0 && i < 48) gload_frag<i / 3>(nxt[i / 3], voff, nbase);
+            });
+            // ... they have landed here: the epilogue below is ordinary compiler code, which may move or
+            // spill registers it believes ready (an asm load's destination must be waited for before that)
+            if constexpr (STEP + 1 < 6) vm_wait_all(nxt);
+            if constexpr (!SWAP) {
+                // Q (steps 0, 1) / K (steps 2, 3): row m, features 256 (STEP / 2) + 64 w + 32 (STEP % 2) + 16 hh .. + 15
+                constexpr int n0 = 256 * (STEP / 2) + 32 * (STEP % 2);
+                float4 b4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bq + n0 + 64 * wave + 16 * hh + 4 * q);
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    const int m = m0 + 32 * t + tok;
+                    if (m >= a.M) continue;
+                    char* dst = a.qk_out + ((size_t)m * 2 * HID + n0 + 64 * wave + 16 * hh) * 2;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
+                        *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{
+                            P::pack2(acc[t][8 * s2 + 0] + ba.x, acc[t][8 * s2 + 1] + ba.y), P::pack2(acc[t][8 * s2 + 2] + ba.z, acc[t][8 * s2 + 3] + ba.w),
+                            P::pack2(acc[t][8 * s2 + 4] + bb.x, acc[t][8 * s2 + 5] + bb.y), P::pack2(acc[t][8 * s2 + 6] + bb.z, acc[t][8 * s2 + 7] + bb.w)};
+                    }
+                }
+            } else {
+                // V: lane = V^T row 64 w + 32 (STEP - 4) + (l & 31) (natural feature pair_row(row): attn_kernel's
+                // tile order), registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of
+                // every 32-token group of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
+                const int vrow = 64 * wave + 32 * (STEP - 4) + tok;
+                const float bv = bq[2 * HID + pair_row(vrow)];
+                char* rowp = a.vt_out + (size_t)vrow * a.vt_ld * 2;
+#pragma unroll
+                for (int t = 0; t < TB; ++t) {
+                    if (valigned[t]) {        // the block is one 32-token group: (q, q + 2) are 8 consecutive columns
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+                            *reinterpret_cast<u32x4*>(rowp + (size_t)(vcol[t][0] + 16 * s2 + 8 * hh) * 2) = u32x4{
+                                P::pack2(acc[t][4 * s2 + 0] + bv, acc[t][4 * s2 + 1] + bv), P::pack2(acc[t][4 * s2 + 2] + bv, acc[t][4 * s2 + 3] + bv),
+                                P::pack2(acc[t][4 * (s2 + 2) + 0] + bv, acc[t][4 * (s2 + 2) + 1] + bv), P::pack2(acc[t][4 * (s2 + 2) + 2] + bv, acc[t][4 * (s2 + 2) + 3] + bv)};
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (vcol[t][h] < 0) continue;
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                const int q = 2 * h + s2;
+                                *reinterpret_cast<uint2*>(rowp + (size_t)(vcol[t][h] + 8 * (2 * s2 + hh)) * 2) = make_uint2(
+                                    P::pack2(acc[t][4 * q + 0] + bv, acc[t][4 * q + 1] + bv), P::pack2(acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv));
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        step(std::integral_constant<int, 0>{}, w1f, w2f);
+        step(std::integral_constant<int, 1>{}, w2f, w1f);
+        step(std::integral_constant<int, 2>{}, w1f, w2f);
+        step(std::integral_constant<int, 3>{}, w2f, w1f);
+        step(std::integral_constant<int, 4>{}, w1f, w2f);
+        step(std::integral_constant<int, 5>{}, w2f, w1f);
+        pstamp(6);
+    }
+}
+
+template <class P>
+hipError_t launch_layer32_p(const Layer32Args& a, hipStream_t s) {
+    if (a.F % HC || a.F < HC || a.M <= 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)L_B1 + (size_t)a.F * 4;
+    if (lds > 163840) return hipErrorInvalidValue;
+    const dim3 grid((a.M + TB * 32 - 1) / (TB * 32));
+    auto launch = [&](auto kern) {
+        static ppg::LdsLimit limit;
+        const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return hipGetLastError();
+    };
+    if (a.wq_img != nullptr) return launch(layer32_kernel<P, true>);
+    return launch(layer32_kernel<P, false>);
+}
+
+}  // namespace
+
+namespace ppg {
+
+hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s) {
+    if (precision == PPG_PRECISION_BF16) return launch_layer32_p<PrecBF16>(a, s);
+    if (precision == PPG_PRECISION_FP16) return launch_layer32_p<PrecF16>(a, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ppg

@@ -14,7 +14,7 @@ import torch
 from . import config, weights
 
 PPG_MAX_LAYERS = 16
-PRECISIONS = {'fp32': 0, 'bf16': 1}
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2}
 KERNEL_CLASSES = (
     'gather', 'inconv', 'qkv', 'attention', 'outproj_ln', 'ffn',
     'outconv_softmax', 'frontend')
