@@ -1,24 +1,37 @@
 """Benchmark of the PPG hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--precision bf16|fp16|fp32]
 
-One step = one pass of the whole hot path over one batch of synthetic input
-that is already resident in HBM: mel frontend (STFT + mel + log) -> 5-layer
-transformer encoder with the reference's 500/50 chunking -> per-frame softmax,
-for BASELINE.json configs[1]: mel representation, batch = 32 x 1000 frames
-(32 x 160000 samples of 16 kHz audio), bf16 MFMA arithmetic.  Weights are a
-seeded random checkpoint of the reference architecture (no network).
+Default workload = BASELINE.json configs[1] ("c2"): one step = one pass of the
+whole hot path over one batch of synthetic input that is already resident in
+HBM -- mel frontend (STFT + mel + log) -> 5-layer transformer encoder with the
+reference's 500/50 chunking -> per-frame softmax -- for mel representation,
+batch = 32 x 1000 frames (32 x 160000 samples of 16 kHz audio), bf16 MFMA
+operands with fp32 accumulation.  Weights are a seeded random checkpoint of
+the reference architecture (no network).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): utterances are
-independent, so every rank runs its own 32 x 1000 batch (weak scaling, no
-data-path collective); value = frames of all ranks / max-over-ranks time.
+N > 1: one rank per GPU.  Launched by ``python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`` the ranks come from the environment;
+launched bare (``python bench.py --gpus N``) the script spawns the N ranks
+itself.  Either way --gpus must equal the world size and the node must have
+that many GPUs, or the run fails.  Utterances are independent, so every rank
+runs its own 32 x 1000 batch (weak scaling, no data-path collective); value =
+frames of all ranks / max-over-ranks time of exactly K steps between two
+barrier + synchronize brackets.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused
-FFN): algorithmic FLOPs per launch / its mean launch duration measured with
-HIP events on the launch stream inside the timed region.  `cpu_baseline` is
-the CPU oracle (fp32 restatement of the reference path, proven equal to the
-reference modules by tests/test_oracle_golden.py) timed on the host cores on
-a bounded sample of the same workload.
+``--workload c4`` = configs[3]: 10 000 utterances of randint(50, 3001) frames
+(seed 1234), packed under max_frames = 32000, LPT-sharded over the ranks; every
+rank generates and holds ONLY its shard; one step = one pass over the shard
+(frontend + encoder per packed batch); the final gatherv of the posteriors to
+rank 0 (RCCL) is timed separately (``gather_ms``).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the
+layer kernel): algorithmic FLOPs per launch / its mean launch duration
+measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` is the CPU oracle (fp32 restatement of the reference path,
+proven equal to the reference modules by tests/test_oracle_golden.py) timed on
+the host cores on the same 32 x 1000 batch, plus its bf16-autocast variant
+(the arithmetic the reference ships with on CPU).
 """
 import argparse
 import json
@@ -37,67 +50,98 @@ BATCH = 32
 FRAMES = 1000
 SAMPLES = FRAMES * 160
 EVENT_STRIDE = 6               # roofline leg: HIP events around every 6th layer-kernel launch of the timed region
-PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_16BIT_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
 PEAK_FP32_TFLOPS = 157.3
+HIDDEN, FFN, LAYERS = 256, 2048, 5
 
 
-def parse():
+def parse(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=50)
-    parser.add_argument('--warmup', type=int, default=10)
-    parser.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
-    parser.add_argument('--cpu-seconds', type=float, default=12.0,
+    parser.add_argument('--steps', type=int, default=None)
+    parser.add_argument('--warmup', type=int, default=None)
+    parser.add_argument('--workload', default='c2', choices=['c2', 'c4'])
+    parser.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    parser.add_argument('--utterances', type=int, default=10000, help='c4: corpus size')
+    parser.add_argument('--cpu-seconds', type=float, default=20.0,
                         help='budget of the CPU-baseline leg')
     parser.add_argument('--no-cpu', action='store_true')
-    return parser.parse_args()
+    parser.add_argument('--no-alt', action='store_true', help='skip the fp16-operand leg of c2')
+    args = parser.parse_args(argv)
+    if args.steps is None:
+        args.steps = 1000 if args.workload == 'c2' else 3      # ~1 s of timed work by default
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == 'c2' else 1
+    return args
+
+
+###############################################################################
+# CPU baseline (rank 0, one GPU only)
+###############################################################################
 
 
 def cpu_baseline(state, seconds):
-    """Oracle (CPU port of the reference path, fp32, autocast off) on a
-    bounded sample: batches of 4 x 160000 samples for about `seconds`, at the
-    torch thread count that is fastest on this host (the default -- one thread
-    per logical core -- oversubscribes the small GEMMs)."""
+    """The oracle (CPU port of the reference path) on the REAL 32 x 1000
+    batch: thread sweep up to the physical cores on one batch each, then the
+    best setting timed on whole batches until the budget is used; fp32
+    (autocast off: the parity definition) and the bf16-autocast variant (what
+    the reference ships with on CPU, ppgs/core.py:586)."""
     from oracle import ppg_oracle
     generator = torch.Generator().manual_seed(1234)
-    audio = 0.1 * torch.randn(4, 1, SAMPLES, generator=generator)
+    audio = 0.1 * torch.randn(BATCH, 1, SAMPLES, generator=generator)
     default_threads = torch.get_num_threads()
-    best = (float('inf'), default_threads)
-    for threads in sorted({default_threads, 64, 32, 16}):
-        if threads > default_threads:
-            continue
-        torch.set_num_threads(threads)
-        ppg_oracle.from_audio(state, audio[:1, :, :16000])      # warm-up
-        start = time.perf_counter()
-        ppg_oracle.from_audio(state, audio[:2])
-        best = min(best, (time.perf_counter() - start, threads))
-    torch.set_num_threads(best[1])
-    start = time.perf_counter()
-    batches = 0
-    while True:
-        ppg_oracle.from_audio(state, audio)
-        batches += 1
-        elapsed = time.perf_counter() - start
-        if elapsed > seconds or batches >= 64:
+    logical = os.cpu_count() or default_threads
+    physical = max(logical // 2, 1)
+    ppg_oracle.from_audio(state, audio[:1, :, :16000])           # warm-up
+    sweep = {}
+    budget_start = time.perf_counter()
+    for threads in sorted({t for t in (8, 16, 32, 64, 128, physical) if t <= logical}):
+        if time.perf_counter() - budget_start > 0.5 * seconds:
             break
+        torch.set_num_threads(threads)
+        start = time.perf_counter()
+        ppg_oracle.from_audio(state, audio)
+        sweep[threads] = time.perf_counter() - start
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+
+    def timed(fn, budget):
+        start = time.perf_counter()
+        batches = 0
+        while True:
+            fn()
+            batches += 1
+            elapsed = time.perf_counter() - start
+            if elapsed > budget or batches >= 8:
+                return batches, elapsed
+    batches, elapsed = timed(lambda: ppg_oracle.from_audio(state, audio), 0.3 * seconds)
+
+    def autocast():
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            ppg_oracle.from_audio(state, audio)
+    autocast()
+    ab, ae = timed(autocast, 0.15 * seconds)
     torch.set_num_threads(default_threads)
     return {
-        'value': batches * 4 * FRAMES / elapsed,
+        'value': batches * BATCH * FRAMES / elapsed,
         'unit': 'frames/s',
-        'cores': best[1],
+        'cores': best,
         'kind': 'port',
-        'sample': f'{batches} batches of 4 x {FRAMES} frames '
-                  f'(mel frontend + encoder + softmax, fp32 CPU oracle), '
-                  f'{elapsed:.1f} s with {best[1]} torch threads on '
-                  f'{os.cpu_count()} logical cores',
+        'sample': f'{batches} batches of {BATCH} x {FRAMES} frames (the benchmark batch; mel frontend + '
+                  f'encoder + softmax, fp32 CPU oracle), {elapsed:.1f} s with {best} torch threads '
+                  f'(best of the sweep {{threads: s/batch}} = '
+                  f'{ {k: round(v, 2) for k, v in sweep.items()} }) on {logical} logical cores',
+        'bf16_autocast_value': ab * BATCH * FRAMES / ae,
+        'bf16_autocast_sample': f'{ab} batches, {ae:.1f} s, same threads, torch.autocast(cpu, bfloat16)',
     }
 
 
-def pmc_traffic(kernel='ffn_'):
+def pmc_traffic(kernel):
     """HBM-side bytes per launch of the dominant kernel from the newest
     committed rocprofv3 PMC summary (profiles/r*_pmc_summary.txt; separate
     --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 reports half of
-    a wide coalesced read, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB."""
+    a wide coalesced read, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB.
+    Not measurable inside this process: null when no summary names the kernel."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.txt')))
@@ -107,46 +151,67 @@ def pmc_traffic(kernel='ffn_'):
     lines = [line for line in open(files[-1]) if line.startswith(kernel)]
     # several variants of the kernel in one run: the one with the Q/K/V tail
     # (4 of the 5 launches of a step) is the one the roofline line describes
-    tail = [line for line in lines if 'true>' in line.split(':')[0]]
+    tail = [line for line in lines if 'true>' in line.split(':')[0] or 'Lb1' in line.split(':')[0]]
     for line in tail or lines:
-        if line.startswith(kernel):
-            m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
-            fetch = float(m.group(1)) if m else fetch
-            m = re.search(r'WRITE_SIZE=([0-9.e+]+)', line)
-            write = float(m.group(1)) if m else write
+        m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
+        fetch = float(m.group(1)) if m else fetch
+        m = re.search(r'WRITE_SIZE=([0-9.e+]+)', line)
+        write = float(m.group(1)) if m else write
     if fetch is None or write is None:
         return None
     return (2.0 * fetch + write) * 1024.0
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
-    torch.cuda.set_device(local_rank)
-    # (PPGS_BENCH_FORCE_DIST=1: exercise the RCCL barrier / max-over-ranks path with one rank)
-    use_dist = world > 1 or bool(os.environ.get('PPGS_BENCH_FORCE_DIST'))
-    if use_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+###############################################################################
+# Workloads
+###############################################################################
 
+
+def layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer):
+    """Algorithmic FLOPs per processed frame of one layer-kernel launch (SURVEY.md
+    8(d)): FFN 4*H*F; + the out-projection 2*H*H when it is fused into the
+    kernel (no separate out-proj launch shows up); + the NEXT layer's Q/K/V
+    projection 6*H*H for all launches but the last layer's (mean over the 5)."""
+    op_fused = kernels['outproj_ln'][1] == 0
+    qkv_own = kernels['qkv'][1] / breakdown_steps / launches_per_layer
+    qkv_fused_layers = max(LAYERS - qkv_own, 0.0) if op_fused else 0.0
+    return (4.0 * HIDDEN * FFN + (2.0 * HIDDEN * HIDDEN if op_fused else 0.0)
+            + 6.0 * HIDDEN * HIDDEN * qkv_fused_layers / LAYERS), op_fused, qkv_fused_layers
+
+
+def run_c2(args, rank, world, local_rank, use_dist):
     import ppgs_amd
     from ppgs_amd import data, engine as E
 
     state = ppgs_amd.weights.seeded_state_dict(seed=1234)
     model = E.Engine(state, local_rank, args.precision)
     generator = torch.Generator().manual_seed(1234 + rank)
-    audio = (0.1 * torch.randn(BATCH, 1, SAMPLES, generator=generator)).cuda()
+    host_audio = (0.1 * torch.randn(BATCH, 1, SAMPLES, generator=generator)).pin_memory()
+    audio = host_audio.cuda(non_blocking=True)
     lengths = [FRAMES] * BATCH
 
-    def step():
+    def step(engine=model):
         mel = ppgs_amd.preprocess.mel.from_audios(audio)
-        return model.encode(mel, lengths)
+        return engine.encode(mel, lengths)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+
+    def timed_block(engine=model):
+        barrier()
+        start = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(engine)
+        barrier()
+        elapsed = time.perf_counter() - start
+        if use_dist:
+            worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            elapsed = float(worst.item())
+        return elapsed, out
 
     out = step()                         # setup: window plan built and uploaded, workspace allocated
     for _ in range(args.warmup):
@@ -159,21 +224,11 @@ def main():
     # through the five launches of a step; two event records per launch cost
     # ~1.5 us each on the stream, 1.5 % of the step if every launch is timed)
     model.profile(True, classes=['ffn'], stride=EVENT_STRIDE)
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
-    start = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
-    elapsed = time.perf_counter() - start
-    if use_dist:
-        worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-        elapsed = float(worst.item())
+    elapsed, out = timed_block()
     ffn_ms, ffn_samples = model.profile_read()['ffn']
+    model.profile(False)
+    # two more blocks of the same K steps: how much the figure moves from block to block
+    repeats = [1e3 * timed_block()[0] / args.steps for _ in range(2)]
     # untimed extra pass: per-kernel-class breakdown (events around every launch)
     breakdown_steps = 5
     model.profile(True)
@@ -186,77 +241,263 @@ def main():
     model.profile(False)
     E.frontend_profile(local_rank, False)
 
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        frames_per_s = world * BATCH * FRAMES * args.steps / elapsed
-        _, info = E.plan_windows(BATCH, FRAMES, lengths)
-        hidden, ffn = 256, 2048
-        # FLOPs of ONE launch: the batch's FFN work of one layer, divided by the
-        # launches per layer (>1 when the engine splits the batch over streams)
-        launches_per_layer = max(kernels['ffn'][1] // (5 * breakdown_steps), 1)
-        # (FFN 2*2*H*F per processed frame; the attention
-        # out-projection's 2*H*H ride along when the engine fuses it into the
-        # same kernel -- then no separate out-proj launch shows up)
-        # and so does the NEXT layer's Q/K/V projection (6*H*H) in all but the last
-        # layer's launch when that is fused as the kernel's tail (then only layer
-        # 0 launches a Q/K/V kernel of its own); flops_per_launch is the mean
-        # over the five launches of a step
-        layers = 5
-        op_fused = kernels['outproj_ln'][1] == 0
-        qkv_own = kernels['qkv'][1] / breakdown_steps / launches_per_layer    # stand-alone Q/K/V launches per step
-        qkv_fused_layers = max(layers - qkv_own, 0.0) if op_fused else 0.0
-        flops_per_frame = (4.0 * hidden * ffn + (2.0 * hidden * hidden if op_fused else 0.0)
-                           + 6.0 * hidden * hidden * qkv_fused_layers / layers)
-        ffn_flops = flops_per_frame * info.processed_frames / launches_per_layer
-        ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_samples, 1)) / 1e12
-        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_FP32_TFLOPS
-        step_flops = BATCH * data.flops(FRAMES)
-        line = {
-            'metric': 'PPG frames/sec (whole node), mel repr, batch=32x1000 frames',
-            'value': frames_per_s,
-            'unit': 'frames/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': ms_per_step,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': args.precision,
-            'data': 'synthetic 16 kHz audio (0.1*randn, seed 1234), '
-                    'seeded random weights of the reference architecture',
-            'config': {
-                'workload': 'configs[1]: mel representation, batch=32 x 1000 '
-                            'frames per GPU, audio resident in HBM -> '
-                            '(32,40,1000) fp32 posteriors in HBM',
-                'batch': BATCH, 'frames': FRAMES, 'per_gpu_batches': 1,
-                'parallelism': f'utterance-sharded x{world}, no data-path collective',
-            },
-            'roofline': {
-                'kernel': ('ffn_mixed_kernel (the layer kernel at this shape: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
-                           + (', next layer Q/K/V)' if qkv_fused_layers else ')') if op_fused
-                           else 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)'),
-                'bound': 'mfma',
-                'achieved': ffn_tflops,
-                'peak': peak,
-                'unit': 'TFLOP/s',
-                'frac': ffn_tflops / peak,
-                'traffic': pmc_traffic(),
-                'flops_per_launch': ffn_flops,
-                'mean_launch_ms': ffn_ms / max(ffn_samples, 1),
-                'timed_launches': ffn_samples,
-            },
-            'end_to_end_tflops': step_flops * args.steps / elapsed / 1e12,
-            'end_to_end_mfma_frac': step_flops * args.steps / elapsed / 1e12 / peak,
-            'kernel_ms_per_step': {
-                k: v[0] / breakdown_steps for k, v in kernels.items()},
-        }
-        if world == 1 and not args.no_cpu:
-            line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
-            line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
-        print(json.dumps(line))
+    # host <-> device legs, timed on their own (never part of `value`): pinned audio H2D, posteriors D2H
+    host_out = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+    copies = {}
+    for name, fn in (('h2d_ms', lambda: audio.copy_(host_audio, non_blocking=True)),
+                     ('d2h_ms', lambda: host_out.copy_(out, non_blocking=True))):
+        fn()
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        copies[name] = 1e3 * (time.perf_counter() - start) / 10
+
+    alt = None
+    if rank == 0 and world == 1 and not args.no_alt and args.precision == 'bf16':
+        # the same step with fp16 MFMA operands (same MFMA rate, 8x smaller operand rounding)
+        other = E.Engine(state, local_rank, 'fp16')
+        for _ in range(max(args.warmup, 3)):
+            step(other)
+        alt_elapsed, alt_out = timed_block(other)
+        alt = {'dtype': 'fp16 operands, fp32 accumulate', 'ms_per_step': 1e3 * alt_elapsed / args.steps,
+               'value': BATCH * FRAMES * args.steps / alt_elapsed,
+               'max_abs_vs_bf16': float((alt_out - out).abs().max())}
+        del other
+
+    if rank != 0:
+        return None
+    ms_per_step = 1e3 * elapsed / args.steps
+    frames_per_s = world * BATCH * FRAMES * args.steps / elapsed
+    _, info = E.plan_windows(BATCH, FRAMES, lengths)
+    launches_per_layer = max(kernels['ffn'][1] // (LAYERS * breakdown_steps), 1)
+    flops_per_frame, op_fused, qkv_fused_layers = layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer)
+    ffn_flops = flops_per_frame * info.processed_frames / launches_per_layer
+    ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_samples, 1)) / 1e12
+    peak = PEAK_FP32_TFLOPS if args.precision == 'fp32' else PEAK_16BIT_TFLOPS
+    step_flops = BATCH * data.flops(FRAMES)
+    layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
+    kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
+                   'W1+ReLU+W2+residual+LN2' + (', next layer Q/K/V)' if qkv_fused_layers else ')')) if layer32 else (
+        'ffn_mixed_kernel (token-split layer kernel: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
+        + (', next layer Q/K/V)' if qkv_fused_layers else ')') if op_fused
+        else 'ffn_kernel (fused W1+ReLU+W2+residual+LayerNorm)')
+    line = {
+        'metric': 'PPG frames/sec (whole node), mel repr, batch=32x1000 frames',
+        'value': frames_per_s,
+        'unit': 'frames/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': args.precision,
+        'data': 'synthetic 16 kHz audio (0.1*randn, seed 1234), '
+                'seeded random weights of the reference architecture',
+        'config': {
+            'workload': 'configs[1]: mel representation, batch=32 x 1000 '
+                        'frames per GPU, audio resident in HBM -> '
+                        '(32,40,1000) fp32 posteriors in HBM',
+            'batch': BATCH, 'frames': FRAMES, 'per_gpu_batches': 1,
+            'parallelism': f'utterance-sharded x{world}, no data-path collective',
+        },
+        'roofline': {
+            'kernel': kernel_name,
+            'bound': 'mfma',
+            'achieved': ffn_tflops,
+            'peak': peak,
+            'unit': 'TFLOP/s',
+            'frac': ffn_tflops / peak,
+            'traffic': pmc_traffic('layer32_' if layer32 else 'ffn_'),
+            'flops_per_launch': ffn_flops,
+            'mean_launch_ms': ffn_ms / max(ffn_samples, 1),
+            'timed_launches': ffn_samples,
+        },
+        'end_to_end_tflops': step_flops * args.steps / elapsed / 1e12,
+        'end_to_end_mfma_frac': step_flops * args.steps / elapsed / 1e12 / peak,
+        'kernel_ms_per_step': {k: v[0] / breakdown_steps for k, v in kernels.items()},
+        'repeat_blocks_ms_per_step': repeats,
+        'h2d_ms': copies['h2d_ms'],
+        'd2h_ms': copies['d2h_ms'],
+        'pcie_inclusive_ms_per_step': ms_per_step + copies['h2d_ms'] + copies['d2h_ms'],
+    }
+    if alt:
+        line['alt_precision'] = alt
+    if world == 1 and not args.no_cpu:
+        line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
+        line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
+    return line
+
+
+def run_c4(args, rank, world, local_rank, use_dist):
+    """configs[3]: a corpus of ragged utterances, LPT-sharded, every rank
+    holding only its shard; posteriors gathered to rank 0 at the end."""
+    import ppgs_amd
+    from ppgs_amd import config, data, distributed, engine as E
+
+    state = ppgs_amd.weights.seeded_state_dict(seed=1234)
+    model = E.Engine(state, local_rank, args.precision)
+    generator = torch.Generator().manual_seed(1234)
+    frames = torch.randint(50, 3001, (args.utterances,), generator=generator).tolist()
+    shards = distributed.shard_lpt([data.flops(f) for f in frames], world)
+    mine = shards[rank]
+    batches = data.pack_batches([frames[i] for i in mine], 32000)
+    # this rank's padded batches, generated on its own GPU (nobody else ever holds them)
+    device_generator = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    padded = []
+    for batch in batches:
+        longest = max(frames[mine[j]] for j in batch) * config.HOPSIZE
+        block = 0.1 * torch.randn((len(batch), 1, longest), device='cuda', generator=device_generator)
+        for row, j in enumerate(batch):
+            block[row, :, frames[mine[j]] * config.HOPSIZE:] = 0.
+        padded.append(block)
+
+    def one_pass(keep=False):
+        outs = []
+        for batch, block in zip(batches, padded):
+            lens = [frames[mine[j]] for j in batch]
+            mel = ppgs_amd.preprocess.mel.from_audios(block)
+            out = model.encode(mel, lens)
+            if keep:
+                outs.append(torch.cat([out[row, :, :n].T for row, n in enumerate(lens)], dim=0))
+        return outs
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    model.profile(True, classes=['ffn'], stride=1)
+    barrier()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    barrier()
+    elapsed = time.perf_counter() - start
+    ffn_ms, ffn_launches = model.profile_read()['ffn']
+    model.profile(False)
     if use_dist:
-        dist.destroy_process_group()
+        worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        elapsed = float(worst.item())
+    # the only collective of the path: gatherv of the posteriors to rank 0
+    outs = one_pass(keep=True)
+    local = torch.cat(outs, dim=0) if outs else torch.zeros((0, 40), device='cuda')
+    order = [mine[j] for batch in batches for j in batch]
+    barrier()
+    start = time.perf_counter()
+    gathered = distributed.gather_ragged(local, [frames[i] for i in order])
+    barrier()
+    gather_ms = 1e3 * (time.perf_counter() - start)
+    if rank != 0:
+        return None
+    assert sum(len(g) for g in gathered) == args.utterances
+    total_frames = sum(frames)
+    # FLOPs of my own shard's launches (rank 0's) for the roofline of its layer kernel
+    processed = 0
+    for batch in batches:
+        lens = [frames[mine[j]] for j in batch]
+        _, info = E.plan_windows(len(batch), max(lens), lens)
+        processed += info.processed_frames
+    per_frame = 4.0 * HIDDEN * FFN + 2.0 * HIDDEN * HIDDEN + 6.0 * HIDDEN * HIDDEN * (LAYERS - 1) / LAYERS
+    ffn_tflops = per_frame * processed * LAYERS * args.steps / (1e-3 * ffn_ms) / 1e12 if ffn_ms else 0.0
+    peak = PEAK_FP32_TFLOPS if args.precision == 'fp32' else PEAK_16BIT_TFLOPS
+    padded_frames = sum(len(b) * max(frames[mine[j]] for j in b) for b in batches)
+    return {
+        'metric': 'PPG frames/sec (whole node), mel repr, 10k ragged utterances packed under max_frames',
+        'value': total_frames * args.steps / elapsed,
+        'unit': 'frames/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': args.precision,
+        'data': 'synthetic 16 kHz audio (0.1*randn per rank, frame counts randint(50,3001) seed 1234), '
+                'seeded random weights of the reference architecture',
+        'config': {
+            'workload': f'configs[3]: {args.utterances} utterances of 50..3000 frames ({total_frames} frames), packed under '
+                        f'max_frames=32000, LPT-sharded by chunk-aware FLOPs over {world} rank(s), each rank holding only '
+                        'its shard in HBM; one step = one pass over the corpus',
+            'utterances': args.utterances, 'rank0_batches': len(batches),
+            'rank0_padding_efficiency': sum(frames[i] for i in mine) / max(padded_frames, 1),
+            'parallelism': f'utterance-sharded x{world}, gatherv to rank 0 only',
+        },
+        'gather_ms': gather_ms,
+        'gather_bytes': total_frames * 40 * 4,
+        'roofline': {
+            'kernel': 'layer kernel launches of rank 0 (layer32_kernel / token-split kernels by batch size)',
+            'bound': 'mfma', 'achieved': ffn_tflops, 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': ffn_tflops / peak, 'traffic': None,
+            'mean_launch_ms': ffn_ms / max(ffn_launches, 1), 'timed_launches': ffn_launches,
+        },
+    }
+
+
+###############################################################################
+# Rank set-up
+###############################################################################
+
+
+def rank_main(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
+    if args.gpus != world:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'bench.py: rank {rank} wants GPU {local_rank}, the node shows {torch.cuda.device_count()}')
+    torch.cuda.set_device(local_rank)
+    # (PPGS_BENCH_FORCE_DIST=1: exercise the RCCL barrier / max-over-ranks / gather path with one rank)
+    use_dist = world > 1 or bool(os.environ.get('PPGS_BENCH_FORCE_DIST'))
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+    try:
+        line = (run_c2 if args.workload == 'c2' else run_c4)(args, rank, world, local_rank, use_dist)
+        if rank == 0:
+            if use_dist:
+                line['rccl_world_size'] = dist.get_world_size()
+            print(json.dumps(line), flush=True)
+    finally:
+        if use_dist:
+            dist.destroy_process_group()
+
+
+def _spawned(local_rank, args, port):
+    os.environ.update(
+        RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(args.gpus),
+        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    rank_main(args)
+
+
+def main():
+    args = parse()
+    if 'RANK' in os.environ or args.gpus == 1:
+        rank_main(args)                  # launched by torch.distributed.run (or a single rank)
+        return
+    # bare `python bench.py --gpus N`: spawn the N ranks here
+    if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+        found = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but this node shows {found} GPU(s)')
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
 
 
 if __name__ == '__main__':

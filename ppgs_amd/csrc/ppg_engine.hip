@@ -267,6 +267,13 @@ struct PpgEngine {
                     for (int k = 1; k < 15; ++k) if (t[k]) fprintf(stderr, " [%d] %llu", k, t[k] - t[0]);
                     fprintf(stderr, "\n");
                 }
+                if (layer32) {
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned long long* t = h + w * 8;
+                        fprintf(stderr, "layer32 wave %d chunk 4: phase A %llu  barrier %llu  pack+write %llu  barrier %llu  phase B %llu | total %llu\n",
+                                w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+                    }
+                } else
                 for (int w = 0; w < 4; ++w)
                     for (int c = 0; c < 4; ++c) {
                         const unsigned long long* t = h + (w * 4 + c) * 8;

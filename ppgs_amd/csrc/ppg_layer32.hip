@@ -119,6 +119,9 @@ __device__ __forceinline__ void stream(uint32_t b0, uint32_t b1, USE use) {
 // step i = ks * 5 + tb: panel fragment tb * 16 + ks (16 K-steps) / h fragment tb * 8 + ks (8 K-steps)
 struct OffPanel { static constexpr int at(int i) { return ((i % TB) * 16 + i / TB) * 1024; } };
 struct OffH { static constexpr int at(int i) { return ((i % TB) * 8 + i / TB) * 1024; } };
+// FFN phase A in two groups: token blocks 0..2 (step i = ks * 3 + tb), then 3..4 (step i = ks * 2 + tb - 3)
+struct OffPanelA { static constexpr int at(int i) { return ((i % 3) * 16 + i / 3) * 1024; } };
+struct OffPanelB { static constexpr int at(int i) { return ((3 + i % 2) * 16 + i / 2) * 1024; } };
 
 __device__ __forceinline__ float pair_sum(float v) {          // lanes l and l + 32
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -175,14 +178,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     f32x16 yacc[2][TB];
-    // parameters
-    for (int i = tid; i < a.F / 4; i += 256)
-        reinterpret_cast<float4*>(smem + L_B1)[i] = reinterpret_cast<const float4*>(a.b1)[i];
-    for (int i = tid; i < 3 * HID / 4; i += 256) {
+    // parameters: every global load first, the LDS stores afterwards (one memory round trip, not three)
+    {
+        const int i = tid;                       // 192 float4 per parameter triple
         const int v = i / (HID / 4), j = i - v * (HID / 4);
-        reinterpret_cast<float4*>(lnp1)[i] = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
-        reinterpret_cast<float4*>(lnp2)[i] = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
-        if constexpr (QKV) reinterpret_cast<float4*>(smem + L_BQ)[i] = reinterpret_cast<const float4*>(a.bq)[i];
+        float4 p1 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p1, pq = p1;
+        if (i < 3 * HID / 4) {
+            p1 = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
+            p2 = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
+            if constexpr (QKV) pq = reinterpret_cast<const float4*>(a.bq)[i];
+        }
+        constexpr int B1MAX = 8;                 // F <= 8192
+        float4 pb[B1MAX];
+#pragma unroll
+        for (int u = 0; u < B1MAX; ++u)
+            if (tid + 256 * u < a.F / 4) pb[u] = reinterpret_cast<const float4*>(a.b1)[tid + 256 * u];
+        if (i < 3 * HID / 4) {
+            reinterpret_cast<float4*>(lnp1)[i] = p1;
+            reinterpret_cast<float4*>(lnp2)[i] = p2;
+            if constexpr (QKV) reinterpret_cast<float4*>(smem + L_BQ)[i] = pq;
+        }
+#pragma unroll
+        for (int u = 0; u < B1MAX; ++u)
+            if (tid + 256 * u < a.F / 4) reinterpret_cast<float4*>(smem + L_B1)[tid + 256 * u] = pb[u];
     }
     // ---- W_o fragments of this wave (2 row blocks x 16 K-steps) straight to registers.  Issued
     // only now: registers written by an asm load must not be spilled before the data is in, and
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * 2 * 4 * 256) + lane * 4;   // this lane's X32 slots
     auto layer_norm = [&](auto residual_tag, const float* lnp, auto emit) {
         constexpr bool RES = decltype(residual_tag)::value;
+        constexpr int STAMP = RES ? 7 : 9;
         float4 bias4[2][4];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -272,7 +291,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 gv[rb][q] = *reinterpret_cast<const float4*>(lnp + HID + n);
                 ev[rb][q] = *reinterpret_cast<const float4*>(lnp + 2 * HID + n);
             }
+        pstamp(STAMP);
         __syncthreads();
+        pstamp(STAMP + 1);
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const float* s = stats + 32 * t + tok;
@@ -313,6 +334,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- FFN: per 128-hidden chunk  h = relu(W1c x1 + b1c)  (phase A),  y += W2c h  (phase B) ---
     for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
+#ifdef PPG_FFN_TIMING
+        auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#else
+        auto cstamp = [&](int) {};
+#endif
+        cstamp(0);
         f32x16 bias;            // C operand of the chunk's first MFMAs: b1 of the lane's 16 hidden rows
         {
             u32x4 braw[4];
@@ -329,25 +356,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         vm_wait_all(w1f);
         const char* w2base = a.w2_img + ((size_t)c * 4 + wave) * 16384;
         f32x16 hacc[TB];
-        stream<OffPanel, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+        // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
+        auto h_write = [&](auto t_tag, auto s_tag) {
+            constexpr int t = decltype(t_tag)::value, s2 = decltype(s_tag)::value;
+            const u32x4 frag = u32x4{P::relu2(P::pack2(hacc[t][8 * s2 + 0], hacc[t][8 * s2 + 1])), P::relu2(P::pack2(hacc[t][8 * s2 + 2], hacc[t][8 * s2 + 3])),
+                                     P::relu2(P::pack2(hacc[t][8 * s2 + 4], hacc[t][8 * s2 + 5])), P::relu2(P::pack2(hacc[t][8 * s2 + 6], hacc[t][8 * s2 + 7]))};
+            const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
+            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
+        };
+        // token blocks 0..2 first (48 steps), then 3..4 (32 steps) with the h of the first three packed
+        // and written between their MFMAs: only two blocks' worth of packing is left after the stream
+        stream<OffPanelA, 16 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
-            constexpr int ks = i / TB, tb = i % TB;
+            constexpr int ks = i / 3, tb = i % 3;
             if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
             else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-            // this chunk's W2 fragments, one load per 5 MFMAs
-            if constexpr (tb == 2) gload_frag<ks>(w2f[ks], voff, w2base);
+            // this chunk's W2 fragments
+            if constexpr (i % 5 == 2) gload_frag<i / 5>(w2f[i / 5], voff, w2base);
         });
-        __syncthreads();                     // every wave is done reading the previous chunk's h
-#pragma unroll
-        for (int t = 0; t < TB; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const u32x4 frag = u32x4{P::relu2(P::pack2(hacc[t][8 * s + 0], hacc[t][8 * s + 1])), P::relu2(P::pack2(hacc[t][8 * s + 2], hacc[t][8 * s + 3])),
-                                         P::relu2(P::pack2(hacc[t][8 * s + 4], hacc[t][8 * s + 5])), P::relu2(P::pack2(hacc[t][8 * s + 6], hacc[t][8 * s + 7]))};
-                asm volatile("ds_write_b128 %0, %1" :: "v"(hb0 + (uint32_t)((t * 8 + 2 * wave + s) * 1024)), "v"(frag) : "memory");
-            }
+        cstamp(1);
+        stream<OffPanelB, 16 * 2, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int ks = i / 2, tb = 3 + i % 2;
+            // (every wave is long done reading the previous chunk's h: the barrier costs its instruction)
+            if constexpr (i == 0) __builtin_amdgcn_s_barrier();
+            if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+            else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+            if constexpr (i % 5 == 2 && 10 + i / 5 < 16) gload_frag<10 + i / 5>(w2f[10 + i / 5], voff, w2base);
+            if constexpr (i % 5 == 1 && i / 5 < 6) h_write(std::integral_constant<int, (i / 5) / 2>{}, std::integral_constant<int, (i / 5) % 2>{});
+        });
+        cstamp(2);
+        h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+        h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+        h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
+        h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cstamp(3);
         __syncthreads();
+        cstamp(4);
         vm_wait_all(w2f);
         // next into the W1 registers: the next chunk's fragments; after the last chunk the first
         // step of the Q/K/V tail (or, without a tail, the chunk's own fragments again: harmless)
@@ -361,6 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // the next chunk's W1 fragments, two loads per 10 MFMAs
             if constexpr (tb == 1 || tb == 3) gload_frag<2 * ks + (tb == 3)>(w1f[2 * ks + (tb == 3)], voff, w1base);
         });
+        cstamp(5);
     }
     vm_wait_all(w1f);
     pstamp(4);

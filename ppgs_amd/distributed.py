@@ -4,9 +4,10 @@ The path shards by utterance with no data-path collective (utterances, and
 even their windows, are independent; weights are replicated).  The only
 exchange is the final gather of results to rank 0 over
 ``torch.distributed`` (backend 'nccl' = RCCL over xGMI on the GPU box,
-'gloo' in the CPU tests): one all_gather of per-rank frame counts, then one
-padded all_gather of the (sum frames, 40) payload.  Not present in the
-reference, which is single-device.
+'gloo' in the CPU tests): one all_gather of per-rank frame counts, then a
+gatherv of the (sum frames, 40) payloads -- grouped point-to-point sends, only
+rank 0 receives, each peer over its own link.  Not present in the reference,
+which is single-device.
 """
 import os
 
@@ -46,29 +47,49 @@ def init(backend=None):
 
 
 def gather_ragged(local, frame_counts_local, dst=0):
-    """Gather per-rank packed results to rank `dst`.
+    """Gather per-rank packed results to rank `dst` (a gatherv: only `dst`
+    receives, and exactly the bytes each rank holds).
 
     local: (frames_local, C) tensor holding this rank's utterances
     back-to-back (frame-major); frame_counts_local: list of their lengths.
     Returns on rank dst a list (one per rank) of lists of (C, frames)
-    tensors, None elsewhere.  Two collectives in total.
+    tensors, None elsewhere.  One small all_gather_object of the frame counts,
+    then one point-to-point transfer per non-empty peer: grouped
+    ncclSend / ncclRecv on the GPU box (each peer on its own xGMI link to
+    `dst`), isend / irecv under gloo.
     """
     world_size = dist.get_world_size() if dist.is_initialized() else 1
     if world_size == 1:
         return [_split(local, frame_counts_local)]
     rank = dist.get_rank()
-    device = local.device
     counts = [None] * world_size
     dist.all_gather_object(counts, [int(c) for c in frame_counts_local])
     totals = [sum(c) for c in counts]
-    longest = max(max(totals), 1)
-    padded = torch.zeros((longest, local.shape[1]), dtype=local.dtype, device=device)
-    padded[:local.shape[0]] = local
-    buffers = [torch.empty_like(padded) for _ in range(world_size)]
-    dist.all_gather(buffers, padded)
+    local = local.contiguous()
+    ops, buffers = [], {}
+    if rank == dst:
+        for src in range(world_size):
+            if src == dst or totals[src] == 0:
+                continue
+            buffers[src] = torch.empty(
+                (totals[src], local.shape[1]), dtype=local.dtype, device=local.device)
+            ops.append(dist.P2POp(dist.irecv, buffers[src], src))
+    elif totals[rank] > 0:
+        ops.append(dist.P2POp(dist.isend, local, dst))
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
     if rank != dst:
         return None
-    return [_split(buffers[r][:totals[r]], counts[r]) for r in range(world_size)]
+    out = []
+    for src in range(world_size):
+        if src == dst:
+            out.append(_split(local, counts[src]))
+        elif totals[src] == 0:
+            out.append([])
+        else:
+            out.append(_split(buffers[src], counts[src]))
+    return out
 
 
 def _split(packed, counts):
@@ -80,19 +101,32 @@ def _split(packed, counts):
 
 
 def from_audios_sharded(audios, compute=None, gpu=None, max_frames=32000,
-                        checkpoint=None, representation=config.REPRESENTATION):
+                        checkpoint=None, representation=config.REPRESENTATION,
+                        frames=None):
     """PPGs of a list of (1, samples) utterances using every rank.
 
-    Every rank passes the same list; rank r computes the utterances LPT
-    assigns to it (cost = algorithmic FLOPs of the chunked forward), packed
-    into padded batches under `max_frames`; results are gathered to rank 0,
-    which returns a list of (40, frames) tensors in input order (other ranks
-    return None).  `compute(padded_audio, sample_lengths) -> (B, 40, T)` is
-    the per-batch forward; by default the HIP engine.
+    The utterances are LPT-assigned by the algorithmic FLOPs of their chunked
+    forward; rank r packs its shard into padded batches under `max_frames`,
+    runs them, and the results are gathered to rank 0, which returns a list of
+    (40, frames) tensors in input order (other ranks return None).
+
+    `audios` is either the list itself (every rank passes the same list) or,
+    with `frames` (the frame count of every utterance, known to all ranks), a
+    callable ``audios(index) -> (1, samples)`` that a rank calls ONLY for the
+    utterances of its own shard -- no rank then ever holds another rank's
+    audio.  `compute(padded_audio, sample_lengths) -> (B, 40, T)` is the
+    per-batch forward; by default the HIP engine.
     """
     rank = dist.get_rank() if dist.is_initialized() else 0
     world_size = dist.get_world_size() if dist.is_initialized() else 1
-    frames = [a.shape[-1] // config.HOPSIZE for a in audios]
+    if frames is None:
+        sequence = audios
+        frames = [a.shape[-1] // config.HOPSIZE for a in sequence]
+
+        def audios(index):
+            return sequence[index]
+    elif not callable(audios):
+        raise TypeError('with frames=, audios must be a callable index -> audio')
     shards = shard_lpt([data.flops(f) for f in frames], world_size)
     mine = shards[rank]
     if compute is None:
@@ -106,7 +140,7 @@ def from_audios_sharded(audios, compute=None, gpu=None, max_frames=32000,
     results = {}
     for batch in data.pack_batches([frames[i] for i in mine], max_frames):
         indices = [mine[j] for j in batch]
-        padded, lengths = data.collate([audios[i][:1] for i in indices])
+        padded, lengths = data.collate([audios(i)[:1] for i in indices])
         out = compute(padded, lengths)
         for row, index in enumerate(indices):
             results[index] = out[row, :, :frames[index]]
@@ -120,7 +154,7 @@ def from_audios_sharded(audios, compute=None, gpu=None, max_frames=32000,
     gathered = gather_ragged(local.contiguous(), [frames[i] for i in mine])
     if gathered is None:
         return None
-    ordered = [None] * len(audios)
+    ordered = [None] * len(frames)
     for r, shard in enumerate(shards):
         for index, ppg in zip(shard, gathered[r]):
             ordered[index] = ppg

@@ -35,7 +35,26 @@ def worker(rank, port, lengths, result_path):
         seen.append(padded.shape[0])
         return ppg_oracle.from_audio(state, padded)
 
-    out = distributed.from_audios_sharded(audios, compute=compute, max_frames=400)
+    # every rank builds ONLY the utterances of its shard (deterministic per index):
+    # touching another rank's audio is an error
+    shards = distributed.shard_lpt([__import__('ppgs_amd').data.flops(n) for n in lengths], WORLD)
+    touched = []
+
+    def audio_of(index):
+        assert index in shards[rank], (rank, index)
+        touched.append(index)
+        return audios[index]
+
+    out = distributed.from_audios_sharded(audio_of, compute=compute, max_frames=400, frames=list(lengths))
+    assert sorted(touched) == sorted(shards[rank])
+    # the gatherv by itself: ragged payloads, one rank with nothing to send
+    payload = torch.arange(12, dtype=torch.float32).reshape(4, 3) + 100 * rank if rank == 1 else torch.zeros((0, 3))
+    gathered = distributed.gather_ragged(payload, [3, 1] if rank == 1 else [])
+    if rank == 0:
+        assert gathered[0] == [] and [tuple(t.shape) for t in gathered[1]] == [(3, 3), (3, 1)]
+        assert torch.equal(gathered[1][0], (torch.arange(9, dtype=torch.float32).reshape(3, 3) + 100).T)
+    else:
+        assert gathered is None
     if rank == 0:
         torch.save({'out': out, 'batches': seen}, result_path)
     else:

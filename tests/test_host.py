@@ -162,3 +162,20 @@ def test_product_never_imports_reference_or_oracle():
     with pytest.raises(ValueError):
         os.environ.pop('PPGS_AMD_SIMILARITY_MATRIX', None)
         ppgs_amd.core.similarity_matrix()
+
+
+def test_bench_entry_point_fails_loudly_without_the_gpus():
+    """bench.py --gpus N must either run N ranks or fail: never report fewer."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, 'bench.py')
+    if torch.cuda.is_available():
+        pytest.skip('CPU-side check')
+    for argv in (['--gpus', '2'], ['--gpus', '1']):
+        run = subprocess.run([sys.executable, bench] + argv, capture_output=True, text=True)
+        assert run.returncode != 0 and 'bench.py' in (run.stderr + run.stdout)
+        assert '"metric"' not in run.stdout
+    # launched as rank 0 of 2 by a launcher while --gpus says 1: refuse
+    env = dict(os.environ, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0')
+    run = subprocess.run([sys.executable, bench, '--gpus', '1'], capture_output=True, text=True, env=env)
+    assert run.returncode != 0
