@@ -3,9 +3,17 @@ committed reference fixtures.  Run with `pytest -m gpu` on an MI355X.
 
 Tolerances (stated here, per the north star):
 * fp32 mode: posteriors within 1e-4 max-abs of the reference / oracle.
-* bf16 mode: posteriors within 1e-2 max-abs (the reference's own
-  bf16-autocast path deviates ~1e-3 from its fp32 path with these weights;
-  bf16 operands + fp32 accumulation here).
+* 16-bit operand modes (fp32 accumulation, fp32 residual / LayerNorm / softmax).  Where the
+  error comes from is measured stage by stage in tools/precision_attribution.py: it is spread
+  evenly over the operand roundings (weights 1.4e-3, attention output 9e-4, x1/x2/h 7-8e-4
+  each at bf16 on the seeded checkpoint), i.e. it is the format, not one fixable stage.
+  - bf16: 4e-3 max-abs on the seeded checkpoint (measured 2.2e-3 .. 3.2e-3; the reference's
+    OWN shipped arithmetic -- bf16 autocast, fixture g7_glue -- is 2.4e-3 from its fp32 result
+    on these weights); on the sharpened checkpoint (posteriors up to 0.5+) 5e-2, where the
+    reference's shipped arithmetic is 1.3e-2 (C1) / 1.9e-2 (C2) from its fp32 result, and
+    per-frame argmax agreement >= 99.9 % (100 % on frames whose top-2 margin exceeds 0.02).
+  - fp16 (same MFMA rate, 11-bit significand): 1e-3 seeded (measured 3e-4), 5e-3 sharpened
+    (measured 2.8e-3), argmax agreement 100 % at C2 size.
 * frontend: fp16 outputs bit-equal for >= 99.5 % of values, never more than
   1 fp16 ulp apart (a different FFT factorisation flips rare roundings).
 """
@@ -21,7 +29,12 @@ from ppgs_amd import weights as W
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
-BF16_TOL = 1e-2
+BF16_TOL = 4e-3          # seeded checkpoint
+BF16_SHARP_TOL = 5e-2    # sharpened checkpoint (see the module docstring)
+FP16_TOL = 1e-3
+FP16_SHARP_TOL = 5e-3
+TOL = {'fp32': FP32_TOL, 'bf16': BF16_TOL, 'fp16': FP16_TOL}
+SHARP_TOL = {'fp32': FP32_TOL, 'bf16': BF16_SHARP_TOL, 'fp16': FP16_SHARP_TOL}
 
 
 def t(x):
@@ -283,7 +296,7 @@ def test_unfused_ffn_path_agrees(monkeypatch):
     assert np.abs(a - b).max() < 2e-5
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp16'])
 def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
     """Batches above ~6 k token rows run each layer as attention + ONE kernel
     (out-proj + LN1 + FFN + LN2 + next layer's Q/K/V).  Ragged 700-frame items
@@ -321,35 +334,70 @@ def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
     out_pieces = run(pieces, feats, lengths)
     out_no_tail = run(no_tail, feats, lengths)
     out_plain = run(plain, feats, lengths)
-    # tolerances: fp32 = the parity bar; bf16 = what test_bf16_mode allows
-    tol = FP32_TOL if precision == 'fp32' else BF16_TOL
-    same = 2e-5 if precision == 'fp32' else 1e-2      # bf16: x1 is rounded at a different point when kept in registers
+    # the token-split kernels everywhere (the 16-bit default at this size is the feature-split
+    # layer32 kernel: 160-token workgroups, here with a partial last tile, windows that start
+    # at odd 16-token blocks -> the unaligned V^T store path -- and padding blocks)
+    monkeypatch.setenv('PPGS_AMD_LAYER32', '0')
+    token_split = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_LAYER32')
+    out_token_split = run(token_split, feats, lengths)
+    # tolerances: fp32 = the parity bar; 16-bit = what test_16bit_modes allows
+    tol = TOL[precision]
+    if precision != 'fp32':
+        # these weights (seed 99) on white-noise features are harsher than the fixtures: the bound is
+        # what the FORMAT costs here -- the oracle with every MFMA operand rounded where the kernels
+        # round it (tools/precision_attribution.py) -- with 60 % headroom for the summation order
+        dtype = torch.bfloat16 if precision == 'bf16' else torch.float16
+        emulated = O.from_features(state, feats, torch.tensor(lengths),
+                                   quant=lambda stage, x: x.to(dtype).float()).numpy()
+        tol = max(tol, 1.6 * float(np.abs(emulated - ref).max()))
+    same = 2e-5 if precision == 'fp32' else tol       # 16-bit: operands are rounded at different points when kept in registers
     assert np.abs(out - ref).max() < tol
+    assert np.abs(out_token_split - ref).max() < tol
     assert np.abs(out - out_pieces).max() < same
     assert np.abs(out - out_no_tail).max() < same
-    assert np.abs(out - out_plain).max() < 2e-5 + (0 if precision == 'fp32' else 2e-3)   # same arithmetic, other summation order
+    assert np.abs(out - out_token_split).max() < same
+    assert np.abs(out - out_plain).max() < same
     for b, n in enumerate(lengths):
         assert np.allclose(out[b, :, n:], 1 / 40)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_poisoned_workspace(precision):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('shape', ['ragged', 'odd_blocks', 'layer32'])
+def test_poisoned_workspace(precision, shape):
     """Nothing in the scratch workspace is read before it is written: the
-    caller's buffer may hold anything (here: NaN bit patterns).  Windows of 40
-    and 300 frames have odd numbers of 16-token blocks, i.e. V^T pad columns."""
+    caller's buffer may hold anything (here: NaN bit patterns).  'ragged':
+    windows of 40 and 300 frames; 'odd_blocks': every window has 21 16-token
+    blocks (333 frames), so every window's last 32-column V^T group is half
+    written by the projections -- round 1 cleared the wrong columns there in the
+    16-bit modes (the permuted group's unwritten slots are not its linear tail);
+    'layer32': a batch large enough for the feature-split kernel with windows at
+    odd 16-token blocks and a partial last 160-token tile."""
     engine, state = eng(seed=5, precision=precision)
     gen = torch.Generator().manual_seed(12)
-    lengths = [700, 40, 300, 513]
-    feats = torch.randn(4, 80, 700, generator=gen).half()
+    if shape == 'ragged':
+        frames, lengths = 700, [700, 40, 300, 513]
+    elif shape == 'odd_blocks':
+        frames, lengths = 333, [333, 333, 333, 333, 333, 333, 111]
+    else:
+        frames, lengths = 333, [333] * 29 + [111, 17, 333]
+    feats = torch.randn(len(lengths), 80, frames, generator=gen).half()
+    poison = torch.full((96 << 20,), float('nan'), device='cuda')      # what the allocator hands out next
+    del poison
+    fresh = E.Engine(state, 0, precision)                              # its workspace comes from the poisoned pool
+    first = run(fresh, feats, lengths)
+    assert np.isfinite(first).all()
     clean = run(engine, feats, lengths)
     for workspace in engine._workspaces.values():
         workspace.view(torch.int16).fill_(-1)          # 0xffff.. = NaN as bf16, fp16 and fp32
     dirty = run(engine, feats, lengths)
     assert np.isfinite(dirty).all()
-    assert np.array_equal(clean, dirty)
+    assert np.array_equal(clean, dirty) and np.array_equal(clean, first)
+    ref = O.from_features(state, feats, torch.tensor(lengths)).numpy()
+    assert np.abs(clean - ref).max() < TOL[precision]
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp16'])
 def test_fused_layer_kernel_hidden_512(precision):
     """The w2v2fb-shaped network (768 -> 512) through the fused layer kernel
     (32-row weight tiles, 48 Q/K/V tiles, one 16-token block per wave)."""
@@ -361,25 +409,76 @@ def test_fused_layer_kernel_hidden_512(precision):
     assert info.tokens > 2048                        # above the split-hidden regime
     out = run(E.Engine(state, 0, precision), feats, lengths)
     ref = O.from_features(state, feats, torch.tensor(lengths)).numpy()
-    assert np.abs(out - ref).max() < (FP32_TOL if precision == 'fp32' else BF16_TOL)
+    assert np.abs(out - ref).max() < TOL[precision]
 
 
-def test_bf16_mode(golden):
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_16bit_modes(golden, precision):
+    """The throughput modes against the reference fixtures: seeded AND sharpened
+    checkpoint, single window / chunked / causal / hidden 512, and the entry-point
+    fixture captured through the reference's genuine glue (g7_glue), next to the
+    reference's own shipped (bf16 autocast) result on the same input."""
+    tol, sharp_tol = TOL[precision], SHARP_TOL[precision]
     g = golden('g2_single_window')
-    engine, _ = eng(precision='bf16')
+    engine, _ = eng(precision=precision)
+    sharp, _ = eng(seed=4321, sharpen=2.0, precision=precision)
     ppg = run(engine, g['features'], g['lengths'])
-    assert np.abs(ppg - g['ppg']).max() < BF16_TOL
+    assert np.abs(ppg - g['ppg']).max() < tol
     assert np.allclose(ppg.sum(1), 1, atol=1e-5)
+    ppg = run(sharp, g['features'], g['lengths'])
+    assert np.abs(ppg - g['ppg_sharp']).max() < sharp_tol
+    assert (ppg.argmax(1) == g['ppg_sharp'].argmax(1)).mean() >= 0.99
     g3 = golden('g3_chunked')
-    ppg = run(engine, g3['features_a'], g3['lengths_a'])
-    assert np.abs(ppg - g3['ppg_a']).max() < BF16_TOL
-    causal, _ = eng(precision='bf16', causal=True)
+    for tag in 'abc':
+        ppg = run(engine, g3[f'features_{tag}'], g3[f'lengths_{tag}'])
+        assert np.abs(ppg - g3[f'ppg_{tag}']).max() < tol, tag
+    ppg = run(sharp, g3['features_a'], g3['lengths_a'])
+    assert np.abs(ppg - g3['ppg_a_sharp']).max() < sharp_tol
+    causal, _ = eng(precision=precision, causal=True)
     ppg = run(causal, g['features'], g['lengths'])
-    assert np.abs(ppg - g['ppg_causal']).max() < BF16_TOL
-    wide, _ = eng(seed=55, cin=768, hidden=512, precision='bf16')
+    assert np.abs(ppg - g['ppg_causal']).max() < tol
+    wide, _ = eng(seed=55, cin=768, hidden=512, precision=precision)
     g5 = golden('g5_w2v2fb')
     ppg = run(wide, g5['features'], g5['lengths'])
-    assert np.abs(ppg - g5['ppg']).max() < BF16_TOL
+    assert np.abs(ppg - g5['ppg']).max() < tol
+    # entry point (C1) through the reference's own from_audio / from_features glue
+    g7 = golden('g7_glue')
+    mel = ppgs_amd.preprocess.mel.from_audios(t(g7['audio']).cuda())
+    for model, tag, bound in ((engine, '', tol), (sharp, '_sharp', sharp_tol)):
+        ppg = model.encode(mel, [100]).cpu().numpy()
+        ours = np.abs(ppg - g7[f'ppg_fp32{tag}']).max()
+        shipped = np.abs(g7[f'ppg_shipped{tag}'] - g7[f'ppg_fp32{tag}']).max()
+        assert ours < bound, (tag, ours)
+        # never worse than 1.6x what the reference's own shipped arithmetic loses on this input
+        assert ours < 1.6 * shipped, (tag, ours, shipped)
+    ppg = run(engine, g7['batch_features'], g7['batch_lengths'])
+    assert np.abs(ppg - g7['batch_ppg_fp32']).max() < tol
+
+
+def test_c2_sharpened_argmax_agreement(golden):
+    """Config C2 size on the SHARPENED checkpoint (posteriors up to ~0.5): what a
+    downstream user reads off a PPG is the per-frame phoneme ranking.  Fixture
+    g6_sharp_stats holds the reference's fp32 argmax track, its top-1/top-2 margins,
+    and how its own shipped bf16-autocast arithmetic fares on the same batch
+    (99.978 % agreement, 1.9e-2 max-abs)."""
+    g = golden('g6_sharp_stats')
+    gen = torch.Generator().manual_seed(1234)
+    audio = (0.1 * torch.randn(32, 1, 160000, generator=gen)).cuda()
+    mel = ppgs_amd.preprocess.mel.from_audios(audio)
+    ref_arg = t(g['argmax'].astype(np.int64))
+    margin = t(g['margin'].astype(np.float32))
+    assert 0.999 < float(g['shipped_argmax_agreement']) < 1.0 and float(g['shipped_max_abs']) > 1e-2
+    for precision, floor in (('fp32', 1.0), ('fp16', 0.9999), ('bf16', 0.999)):
+        engine, _ = eng(seed=4321, sharpen=2.0, precision=precision)
+        ppg = engine.encode(mel, [1000] * 32).cpu()
+        agree = ppg.argmax(1) == ref_arg
+        assert float(agree.float().mean()) >= floor, precision
+        assert bool(agree[margin > 0.02].all()), precision           # only near-ties may flip
+        tol = SHARP_TOL[precision]
+        assert (ppg[0, :, :64] - t(g['ppg_item0_first64'])).abs().max() < tol
+        assert (ppg[31, :, -64:] - t(g['ppg_item31_last64'])).abs().max() < tol
+        assert (ppg.amax(-1) - t(g['ppg_max'])).abs().max() < tol
+        assert (ppg.mean(-1) - t(g['ppg_mean'])).abs().max() < tol
 
 
 # ------------------------------------------------- full size (config C2) ----
@@ -394,7 +493,7 @@ def test_c2_full_size_statistics(golden):
     mel = ppgs_amd.preprocess.mel.from_audios(audio)
     assert mel.shape == (32, 80, 1000)
     assert np.abs(mel.float().sum(dim=(1, 2)).cpu().numpy() - g['mel_sum']).max() < 2.0
-    for precision, tol in (('fp32', 2e-4), ('bf16', BF16_TOL)):
+    for precision, tol in (('fp32', 2e-4), ('bf16', BF16_TOL), ('fp16', FP16_TOL)):
         engine, _ = eng(precision=precision)
         ppg = engine.encode(mel, [1000] * 32)
         torch.cuda.synchronize()
@@ -405,7 +504,7 @@ def test_c2_full_size_statistics(golden):
         assert np.abs(ppg[0, :, :64].numpy() - g['ppg_item0_first64']).max() < tol
         assert np.abs(ppg[31, :, -64:].numpy() - g['ppg_item31_last64']).max() < tol
         assert np.abs(ppg.mean(-1).numpy() - g['ppg_mean']).max() < tol
-        assert np.abs(ppg.amax(-1).numpy() - g['ppg_max']).max() < 5 * tol
+        assert np.abs(ppg.amax(-1).numpy() - g['ppg_max']).max() < 2 * tol
     # batch-composition invariance: an item computed alone (full length, so
     # no halo difference) equals its row in the batch
     engine, _ = eng()
