@@ -66,18 +66,18 @@ def test_pt_writer_is_torch_loadable(tmp_path):
         E.pt_write_batch(paths[:1], tensor[:1], [300])
 
 
-def test_loader_batches_native_and_fallback(tmp_path):
-    """The loader decodes 16 kHz files natively and falls back to the Python
-    path (resampling) for other rates; both give the collate semantics."""
-    import ppgs_amd
-    if torch.cuda.is_available():
-        pytest.skip('CPU-only check of the loader (pinned memory not needed)')
+def _loader_files(tmp_path, specs):
     rng = np.random.default_rng(3)
     files = []
-    for i, (n, rate) in enumerate(((3200, 16000), (1600, 16000), (2400, 8000))):
+    for i, (n, rate) in enumerate(specs):
         path = tmp_path / f'{i}.wav'
         wavfile.write(path, rate, (0.1 * rng.standard_normal(n)).astype(np.float32))
         files.append(path)
+    return files
+
+
+def _check_loader(files):
+    import ppgs_amd
     batches = list(ppgs_amd.core.loader(files, num_workers=2, max_frames=1000))
     seen = {f for _, _, names in batches for f in names}
     assert seen == set(files)
@@ -87,3 +87,22 @@ def test_loader_batches_native_and_fallback(tmp_path):
             reference = load.audio(name)[0]
             assert torch.allclose(row[0, :length], reference[:length])
             assert row[0, length:].abs().sum() == 0
+
+
+def test_loader_batches_native(tmp_path):
+    """The loader decodes 16 kHz files natively with the collate semantics; a
+    file at another rate needs the resampler, which is the HIP kernel: without a
+    device that must fail loudly, not fall back to a host filter."""
+    import ppgs_amd
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check of the loader (pinned memory not needed)')
+    _check_loader(_loader_files(tmp_path, ((3200, 16000), (1600, 16000), (2000, 16000))))
+    other = _loader_files(tmp_path, ((2400, 8000),))
+    with pytest.raises(ppgs_amd.engine.PpgError):
+        list(ppgs_amd.core.loader(other, num_workers=1, max_frames=1000))
+
+
+@pytest.mark.gpu
+def test_loader_batches_native_and_resampled(tmp_path):
+    """... and with a device the 8 kHz file goes through load.audio + ppg_resample."""
+    _check_loader(_loader_files(tmp_path, ((3200, 16000), (1600, 16000), (2400, 8000))))
