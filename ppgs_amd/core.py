@@ -176,11 +176,19 @@ class loader:
                  max_frames=config.MAX_INFERENCE_FRAMES, mode='sorted'):
         self.files = list(audio_files)
         frames, self.samples, self.rates = [], [], []
+        readable = []
         for file in self.files:
-            samples, rate = load.info(file)
+            # one unreadable file must not abort the job: warn and skip it
+            try:
+                samples, rate = load.info(file)
+            except (ValueError, OSError, engine.PpgError) as error:
+                warnings.warn(f'Skipping {file}: {error}')
+                continue
+            readable.append(file)
             frames.append(data.frames_of(samples, rate))
             self.samples.append(samples)
             self.rates.append(rate)
+        self.files = readable
         budget = max_frames
         keep = data.filter_lengths(frames, budget, self.files)
         self.files = [self.files[i] for i in keep]

@@ -194,8 +194,18 @@ struct DevLayer {
 struct DevPlan {
     Plan host;
     void* buf = nullptr;
+    size_t cap = 0;            // bytes of buf
     uint64_t stamp = 0;
+    bool pinned = false;       // used under stream capture: a HIP graph holds its device pointers, never evicted
+    hipEvent_t uploaded = nullptr;   // recorded behind the asynchronous upload of the tables
+    hipStream_t upload_stream = nullptr;
+    bool upload_done = false;
+    ~DevPlan() { if (uploaded) (void)hipEventDestroy(uploaded); }
 };
+// a device buffer whose last use was ordered before `ready` on some stream
+struct RetiredBuf { void* buf; size_t cap; hipEvent_t ready; };
+// pinned host staging slot of the plan uploads: busy until `done`
+struct StageSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
 
 struct Workspace {
     size_t xw, x, xb, qk, vt, ao, hid, part, total;
@@ -242,6 +252,9 @@ struct PpgEngine {
     std::vector<DevLayer> layers;
     std::map<std::string, std::unique_ptr<DevPlan>> plans;
     uint64_t plan_stamp = 0;
+    std::vector<RetiredBuf> retired;           // evicted plans' buffers: reused (or freed) once their event has passed
+    StageSlot stage[4];
+    int stage_next = 0;
     std::mutex mu;
     // profiling
     unsigned profiling = 0;          // bitmask of kernel classes to time
@@ -306,6 +319,8 @@ struct PpgEngine {
             (void)hipFree(lin_dbg);
         }
         for (auto& kv : plans) if (kv.second->buf) (void)hipFree(kv.second->buf);
+        for (RetiredBuf& r : retired) { (void)hipFree(r.buf); (void)hipEventDestroy(r.ready); }
+        for (StageSlot& st : stage) { if (st.host) (void)hipHostFree(st.host); if (st.done) (void)hipEventDestroy(st.done); }
         for (hipStream_t st : side_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t ev : ev_join) (void)hipEventDestroy(ev);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -442,7 +457,15 @@ size_t finish_plan(const PpgEngine* e, Plan* p) {
     return off;
 }
 
-int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int legacy, DevPlan** out) {
+// The cached (or new) plan of a batch shape, its tables on the device.  A miss costs no device-wide
+// synchronisation: the tables go up by hipMemcpyAsync on `stream` from a pinned staging ring, device
+// buffers of evicted plans are recycled behind an event.  Under stream capture (Engine.graphed)
+// nothing may allocate or copy: the plan must already be cached (graphed() warms it up), and it is
+// pinned from then on -- the graph holds its device pointers.
+int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int legacy, hipStream_t stream, DevPlan** out) {
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capture);
+    const bool capturing = capture != hipStreamCaptureStatusNone;
     std::string key;
     key.reserve(16 + 8 * (size_t)batch);
     const int hdr[3] = {batch, frames, legacy};
@@ -450,10 +473,22 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
     key.append(reinterpret_cast<const char*>(lengths), sizeof(int64_t) * (size_t)batch);
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
-        it->second->stamp = ++e->plan_stamp;
-        *out = it->second.get();
+        DevPlan* hit = it->second.get();
+        hit->stamp = ++e->plan_stamp;
+        if (capturing) hit->pinned = true;
+        // the tables went up asynchronously on the stream of the first use: another stream waits for them
+        if (!hit->upload_done) {
+            if (hipEventQuery(hit->uploaded) == hipSuccess) hit->upload_done = true;
+            else if (stream != hit->upload_stream) {
+                if (capturing) HIP_OK(hipEventSynchronize(hit->uploaded));
+                else HIP_OK(hipStreamWaitEvent(stream, hit->uploaded, 0));
+            }
+        }
+        *out = hit;
         return PPG_OK;
     }
+    if (capturing)
+        return fail(PPG_EINVAL, "ppg_encode under stream capture needs a cached plan: run the same (batch, frames, lengths) once before capturing");
     auto dp = std::make_unique<DevPlan>();
     int rc = build_plan(e->cfg.chunk_length, e->cfg.chunk_overlap, e->cfg.max_positions, batch, frames,
                         lengths, legacy, ppg::attn_query_tile(e->head_dim), &dp->host);
@@ -480,17 +515,58 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
         memcpy(staging.data() + offs[gi].blk, grp.blk_win.data(), grp.blk_win.size() * sizeof(int));
         memcpy(staging.data() + offs[gi].item, grp.items.data(), grp.items.size() * sizeof(AttnItem));
     }
-    // bound the cache: evict the least recently used plan
+    // bound the cache: evict the least recently used plan that no graph refers to; its buffer
+    // is retired behind an event on this stream (kernels already queued may still read it)
     if (e->plans.size() >= 64) {
-        auto victim = e->plans.begin();
+        auto victim = e->plans.end();
         for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt)
-            if (jt->second->stamp < victim->second->stamp) victim = jt;
-        HIP_OK(hipDeviceSynchronize());
-        if (victim->second->buf) (void)hipFree(victim->second->buf);
-        e->plans.erase(victim);
+            if (!jt->second->pinned && (victim == e->plans.end() || jt->second->stamp < victim->second->stamp)) victim = jt;
+        if (victim != e->plans.end()) {
+            if (victim->second->buf) {
+                RetiredBuf r{victim->second->buf, victim->second->cap, nullptr};
+                HIP_OK(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
+                HIP_OK(hipEventRecord(r.ready, stream));
+                e->retired.push_back(r);
+            }
+            e->plans.erase(victim);
+        }
     }
-    HIP_OK(hipMalloc(&dp->buf, total));
-    HIP_OK(hipMemcpy(dp->buf, staging.data(), total, hipMemcpyHostToDevice));
+    // a retired buffer that is large enough and no longer in use, else a new one
+    for (size_t i = 0; i < e->retired.size(); ++i) {
+        RetiredBuf& r = e->retired[i];
+        if (hipEventQuery(r.ready) != hipSuccess) continue;
+        if (r.cap >= total && dp->buf == nullptr) {
+            dp->buf = r.buf; dp->cap = r.cap;
+        } else if (e->retired.size() > 16) {
+            (void)hipFree(r.buf);                 // the pool stays small
+        } else {
+            continue;
+        }
+        (void)hipEventDestroy(r.ready);
+        e->retired.erase(e->retired.begin() + i);
+        --i;
+    }
+    if (dp->buf == nullptr) {
+        dp->cap = align_up(total, 4096);
+        HIP_OK(hipMalloc(&dp->buf, dp->cap));
+    }
+    // upload through a pinned staging slot, asynchronously on the encode stream
+    StageSlot& slot = e->stage[e->stage_next];
+    e->stage_next = (e->stage_next + 1) % 4;
+    if (slot.used) HIP_OK(hipEventSynchronize(slot.done));      // four uploads in flight at most
+    if (slot.cap < total) {
+        if (slot.host) (void)hipHostFree(slot.host);
+        slot.cap = align_up(total * 2, 4096);
+        HIP_OK(hipHostMalloc(&slot.host, slot.cap, hipHostMallocDefault));
+    }
+    if (!slot.done) HIP_OK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    memcpy(slot.host, staging.data(), total);
+    HIP_OK(hipMemcpyAsync(dp->buf, slot.host, total, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipEventRecord(slot.done, stream));
+    slot.used = true;
+    HIP_OK(hipEventCreateWithFlags(&dp->uploaded, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(dp->uploaded, stream));
+    dp->upload_stream = stream;
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         char* base = static_cast<char*>(dp->buf);
         p.groups[gi].d_win = reinterpret_cast<PpgWindow*>(base + offs[gi].win);
@@ -879,7 +955,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream_);
     DevPlan* dp = nullptr;
-    int rc = get_plan(e, batch, frames, lengths, legacy_mode, &dp);
+    int rc = get_plan(e, batch, frames, lengths, legacy_mode, s, &dp);
     if (rc) return rc;
     const Plan& plan = dp->host;
     const PpgConfig& c = e->cfg;

@@ -113,8 +113,32 @@ int wav_parse(FILE* f, const char* path, WavInfo* info) {
                 t_io_error = std::string(path) + ": data chunk before a valid fmt chunk";
                 return PPG_EINVAL;
             }
-            info->samples = size / info->block_align;
+            // the header is not trusted: a frame must hold all its channels' samples (the decoder
+            // reads bits / 8 bytes at every block_align step), and only whole-byte sample sizes exist
+            const int bits = info->bits;
+            if ((bits != 8 && bits != 16 && bits != 24 && bits != 32 && bits != 64) ||
+                info->block_align < info->channels * (bits / 8)) {
+                char buf[128];
+                snprintf(buf, sizeof(buf), ": inconsistent fmt chunk (%d channels, %d bits, block align %d)",
+                         info->channels, bits, info->block_align);
+                t_io_error = std::string(path) + buf;
+                return PPG_EINVAL;
+            }
             info->data_offset = ftell(f);
+            // clamp the data chunk to what the file really holds: streaming writers leave 0 or
+            // 0xFFFFFFFF in the size field, truncated files promise more than they have --
+            // decode what exists, as torchaudio does
+            int64_t available = 0;
+            {
+                const long here = ftell(f);
+                if (here < 0 || fseek(f, 0, SEEK_END)) return PPG_EINVAL;
+                const long end = ftell(f);
+                if (end < here || fseek(f, here, SEEK_SET)) return PPG_EINVAL;
+                available = (int64_t)(end - here);
+            }
+            int64_t bytes = (int64_t)size;
+            if (size == 0 || size == 0xFFFFFFFFu || bytes > available) bytes = available;
+            info->samples = bytes / info->block_align;
             return PPG_OK;
         } else if (fseek(f, (long)(size + (size & 1)), SEEK_CUR)) {
             t_io_error = std::string(path) + ": truncated chunk";
@@ -283,13 +307,17 @@ int pt_write(const char* path, const float* src, int64_t rows, int64_t row_strid
     zip_add(out, dir, "archive/data/0", packed.data(), packed.size() * 4, true);
     zip_add(out, dir, "archive/version", "3\n", 2, false);
     zip_finish(out, dir);
-    FILE* f = fopen(path, "wb");
-    if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) {
-        if (f) fclose(f);
+    // write next to the target and rename: a reader never sees a half-written file, and a
+    // failed flush (disk full) is reported instead of leaving a truncated .pt behind
+    const std::string tmp = std::string(path) + ".tmp~";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    const bool written = f && fwrite(out.data(), 1, out.size(), f) == out.size();
+    const bool closed = f ? fclose(f) == 0 : false;
+    if (!written || !closed || rename(tmp.c_str(), path) != 0) {
+        (void)remove(tmp.c_str());
         t_io_error = std::string("cannot write ") + path;
         return PPG_EINVAL;
     }
-    fclose(f);
     return PPG_OK;
 }
 

@@ -255,9 +255,12 @@ class Engine:
             int(legacy_mode), ctypes.byref(size)))
         return size.value
 
-    def encode(self, features, lengths, softmax=True, legacy_mode=False):
+    def encode(self, features, lengths, softmax=True, legacy_mode=False,
+               workspace=None):
         """features (B, Cin, T) fp16/fp32 on this engine's GPU -> (B, 40, T)
-        fp32 on the same GPU (posteriors, or logits if softmax=False)."""
+        fp32 on the same GPU (posteriors, or logits if softmax=False).
+        `workspace`: a caller-owned uint8 scratch tensor of at least
+        workspace_bytes(); default: one grow-only buffer per HIP stream."""
         if features.dim() != 3 or features.shape[1] != self.input_channels:
             raise ValueError(
                 f'features must be (batch, {self.input_channels}, frames), '
@@ -279,11 +282,19 @@ class Engine:
             stream = torch.cuda.current_stream().cuda_stream
             # encodes issued on different streams may overlap: each stream
             # gets its own scratch buffer (grow-only, reused call to call)
-            workspace = self._workspaces.get(stream)
-            if workspace is None or workspace.numel() < size.value:
-                workspace = torch.empty(
-                    max(size.value, 256), dtype=torch.uint8, device=self.device)
-                self._workspaces[stream] = workspace
+            if workspace is not None:
+                if workspace.numel() < size.value or workspace.device != self.device:
+                    raise ValueError(
+                        f'workspace of {workspace.numel()} bytes, {size.value} needed')
+            else:
+                workspace = self._workspaces.get(stream)
+                if workspace is None or workspace.numel() < size.value:
+                    workspace = torch.empty(
+                        max(size.value, 256), dtype=torch.uint8, device=self.device)
+                    # a buffer allocated under stream capture lives in the graph's
+                    # private pool: never cache it for later eager calls
+                    if not torch.cuda.is_current_stream_capturing():
+                        self._workspaces[stream] = workspace
             out = torch.empty(
                 (batch, self.output_channels, frames), dtype=torch.float32,
                 device=self.device)
@@ -309,21 +320,28 @@ class Engine:
         static_in = torch.zeros(
             (batch, self.input_channels, frames), dtype=feature_dtype,
             device=self.device)
+        # the graph gets a scratch buffer of its own (two graphs of one engine replayed on
+        # different streams must not share one), allocated before the capture starts
+        scratch = torch.empty(
+            max(self.workspace_bytes(batch, frames, lengths, legacy_mode), 256),
+            dtype=torch.uint8, device=self.device)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(2):                       # plan + workspace warm-up
-                self.encode(static_in, lengths, softmax, legacy_mode)
+            for _ in range(2):                       # the window plan is built, uploaded and cached here
+                self.encode(static_in, lengths, softmax, legacy_mode, workspace=scratch)
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            static_out = self.encode(static_in, lengths, softmax, legacy_mode)
+            # (under capture ppg_encode pins the cached plan: the graph holds its device pointers)
+            static_out = self.encode(static_in, lengths, softmax, legacy_mode, workspace=scratch)
 
         def run(features):
             static_in.copy_(features, non_blocking=True)
             graph.replay()
             return static_out
         run.graph = graph
+        run.scratch = scratch
         return run
 
     # -- per-kernel HIP-event timing (bench.py roofline leg) ----------------

@@ -14,14 +14,44 @@ _HUB_REPO = 'CameronChurchwell/ppgs'
 _HUB_FILES = {'mel': 'mel-800k.pt', 'w2v2fb': 'w2v2fb-425k.pt'}
 
 
+def _decode_other(file):
+    """Containers the native RIFF/WAV reader does not handle (the reference
+    decodes mp3 / flac / ogg through torchaudio.load, ppgs/load.py:17-30): use
+    soundfile or torchaudio when one of them is installed."""
+    try:
+        import soundfile
+        data, sample_rate = soundfile.read(os.fspath(file), dtype='float32', always_2d=True)
+        return torch.from_numpy(np.ascontiguousarray(data.T)), int(sample_rate)
+    except ImportError:
+        pass
+    try:
+        import torchaudio
+        samples, sample_rate = torchaudio.load(os.fspath(file))
+        return samples.to(torch.float32), int(sample_rate)
+    except ImportError:
+        raise ValueError(
+            f'{file}: not a RIFF/WAV file, and neither soundfile nor torchaudio '
+            'is installed to decode other containers') from None
+
+
+def _is_riff(file):
+    with open(os.fspath(file), 'rb') as handle:
+        head = handle.read(12)
+    return len(head) == 12 and head[:4] in (b'RIFF', b'RIFX') and head[8:12] == b'WAVE'
+
+
 def audio(file):
-    """Load an audio file as (1, samples) fp32 at 16 kHz.
+    """Load an audio file as (channels, samples) fp32 at 16 kHz.
 
     The reference goes through torchaudio.load + Resample
-    (ppgs/load.py:17-30); here PCM/float WAV is decoded directly and other
-    sample rates are converted by :func:`ppgs_amd.core.resample`.
+    (ppgs/load.py:17-30); here PCM/float WAV is decoded directly, other
+    containers by soundfile / torchaudio if present, and other sample rates
+    are converted by :func:`ppgs_amd.core.resample`.
     """
     from . import core
+    if not _is_riff(file):
+        samples, sample_rate = _decode_other(file)
+        return core.resample(samples, sample_rate)
     from scipy.io import wavfile
     sample_rate, data = wavfile.read(os.fspath(file))
     if data.dtype == np.uint8:
@@ -40,8 +70,12 @@ def audio(file):
 
 def info(file):
     """(num_samples, sample_rate) from the RIFF header, without decoding
-    (the reference uses torchaudio.info, ppgs/data/dataset.py:187)."""
+    (the reference uses torchaudio.info, ppgs/data/dataset.py:187); other
+    containers are decoded to find out."""
     from . import engine
+    if not _is_riff(file):
+        samples, sample_rate = _decode_other(file)
+        return int(samples.shape[-1]), sample_rate
     samples, rate, _ = engine.wav_info(file)
     return samples, rate
 

@@ -699,3 +699,36 @@ def test_graphed_encode_helper():
         torch.cuda.synchronize()
         ref = engine.encode(feats.cuda(), [100] * 4)
         assert (out - ref).abs().max() == 0
+
+
+def test_plan_cache_eviction_and_graph_replay():
+    """More than 64 distinct batch shapes pass through one engine (every ragged
+    batch of a file job is a new shape): evictions must not touch the plan a
+    captured HIP graph refers to, uploads are asynchronous (no device-wide
+    sync), and capturing a shape whose plan is not cached is refused."""
+    engine, state = eng(seed=21, precision='fp16', causal=True)
+    gen = torch.Generator().manual_seed(2)
+    feats = torch.randn(8, 80, 96, generator=gen).half().cuda()
+    replay = engine.graphed(8, 96)
+    second = engine.graphed(8, 96)          # its own scratch: two graphs of one engine do not share one
+    assert replay.scratch.data_ptr() != second.scratch.data_ptr()
+    before = replay(feats).clone()
+    ref = O.from_features(state, feats.cpu(), [96] * 8, is_causal=True).numpy()
+    assert np.abs(before.cpu().numpy() - ref).max() < FP16_TOL
+    for i in range(90):                      # 90 new shapes -> the 64-entry cache turns over
+        frames = 40 + i
+        x = torch.randn(2, 80, frames, generator=gen).half().cuda()
+        out = engine.encode(x, [frames, 17 + (i % 5)])
+        if i % 30 == 0:
+            check = O.from_features(state, x.cpu(), [frames, 17 + (i % 5)], is_causal=True).numpy()
+            assert np.abs(out.cpu().numpy() - check).max() < FP16_TOL
+    after = replay(feats)
+    torch.cuda.synchronize()
+    assert torch.equal(before, after)
+    assert torch.equal(second(feats), after)
+    with pytest.raises((E.PpgError, ValueError, RuntimeError)):
+        graph = torch.cuda.CUDAGraph()
+        fresh = torch.zeros(3, 80, 77, dtype=torch.float16, device='cuda')
+        scratch = torch.empty(engine.workspace_bytes(3, 77, [77, 77, 77]), dtype=torch.uint8, device='cuda')
+        with torch.cuda.graph(graph):
+            engine.encode(fresh, [77, 77, 77], workspace=scratch)

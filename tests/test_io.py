@@ -106,3 +106,58 @@ def test_loader_batches_native(tmp_path):
 def test_loader_batches_native_and_resampled(tmp_path):
     """... and with a device the 8 kHz file goes through load.audio + ppg_resample."""
     _check_loader(_loader_files(tmp_path, ((3200, 16000), (1600, 16000), (2400, 8000))))
+
+
+def _wav_bytes(rate=16000, channels=1, bits=16, block_align=None, data=b'', data_size=None, fmt_tag=1):
+    import struct
+    block_align = channels * bits // 8 if block_align is None else block_align
+    fmt = struct.pack('<HHIIHH', fmt_tag, channels, rate, rate * block_align, block_align, bits)
+    size = len(data) if data_size is None else data_size
+    body = b'WAVE' + b'fmt ' + struct.pack('<I', len(fmt)) + fmt + b'data' + struct.pack('<I', size) + data
+    return b'RIFF' + struct.pack('<I', len(body) & 0xffffffff) + body
+
+
+def test_wav_header_is_not_trusted(tmp_path):
+    """Crafted / damaged RIFF headers: inconsistent block_align is rejected (the decoder
+    would read past its buffer), streaming and truncated data chunks decode what the
+    file really holds, and an unreadable file is skipped by the loader, not fatal."""
+    import ppgs_amd
+    samples = (np.arange(1000) - 500).astype('<i2')
+    good = tmp_path / 'good.wav'
+    good.write_bytes(_wav_bytes(data=samples.tobytes()))
+    assert E.wav_info(good)[:2] == (1000, 16000)
+    # block_align smaller than a frame: 64-bit samples at a 1-byte stride
+    evil = tmp_path / 'evil.wav'
+    evil.write_bytes(_wav_bytes(bits=64, block_align=1, fmt_tag=3, data=b'\\0' * 64))
+    with pytest.raises(ValueError):
+        E.wav_info(evil)
+    odd = tmp_path / 'odd_bits.wav'
+    odd.write_bytes(_wav_bytes(bits=12, block_align=2, data=b'\\0' * 64))
+    with pytest.raises(ValueError):
+        E.wav_info(odd)
+    # streaming writer: size field 0xFFFFFFFF (or 0) -> what follows in the file
+    for tag, size in (('ffff', 0xFFFFFFFF), ('zero', 0)):
+        stream = tmp_path / f'stream_{tag}.wav'
+        stream.write_bytes(_wav_bytes(data=samples.tobytes(), data_size=size))
+        assert E.wav_info(stream)[0] == 1000
+    # truncated: the header promises 1000 samples, 300 are there
+    cut = tmp_path / 'cut.wav'
+    cut.write_bytes(_wav_bytes(data=samples[:300].tobytes(), data_size=2000))
+    assert E.wav_info(cut)[0] == 300
+    padded, lengths, _ = E.wav_read_batch([str(good), str(cut)], 1000, threads=2, pin_memory=False)
+    assert lengths.tolist() == [1000, 300]
+    assert torch.equal(padded[1, 0, :300], torch.from_numpy(samples[:300].astype(np.float32) / 32768))
+    assert padded[1, 0, 300:].abs().sum() == 0
+    # the loader skips what it cannot read and keeps going
+    junk = tmp_path / 'junk.wav'
+    junk.write_bytes(b'not audio at all')
+    with pytest.warns(UserWarning):
+        batches = list(ppgs_amd.core.loader([good, junk, evil, cut], num_workers=1, max_frames=1000))
+    seen = sorted(str(f) for _, _, names in batches for f in names)
+    assert seen == sorted([str(good), str(cut)])
+    # the .pt writer replaces atomically and leaves no temporary behind
+    out = tmp_path / 'x.pt'
+    E.pt_write_batch([str(out)], torch.zeros(1, 40, 5), [5], 1)
+    assert torch.load(out).shape == (40, 5) and not list(tmp_path.glob('*.tmp~'))
+    with pytest.raises(ValueError):
+        E.pt_write_batch([str(tmp_path / 'no_such_dir' / 'y.pt')], torch.zeros(1, 40, 5), [5], 1)
