@@ -34,6 +34,14 @@ PRECISION = os.environ.get('PPGS_AMD_PRECISION', 'fp16')
 # reference default of infinity (which would put every file in one batch).
 DEFAULT_BATCH_FRAMES = 262144
 
+# How from_files_to_files packs files into padded batches: 'sorted' (default:
+# length-homogeneous batches under the same B * maxlen <= max_frames rule) or
+# 'reference' (the reference Sampler's seeded shuffle and greedy packing, bit
+# for bit -- fixture G8 -- including ONE batch of everything when max_frames is
+# infinite: the longest item of a batch sets every other item's halo frames, so
+# this is the switch for reproducing the reference's per-file numbers exactly).
+PACKING_MODE = os.environ.get('PPGS_AMD_PACKING', 'sorted')
+
 _engines = {}
 
 
@@ -154,7 +162,7 @@ def from_files_to_files(audio_files, output_files,
         return
     dataloader = loader(
         audio_files, num_workers=max(num_workers // 2, 1),
-        max_frames=max_frames)
+        max_frames=max_frames, mode=PACKING_MODE)
     mapping = dict(zip(audio_files, output_files))
     from_dataloader(
         dataloader=dataloader, output_files=mapping,
@@ -195,7 +203,7 @@ class loader:
         self.frames = [frames[i] for i in keep]
         self.samples = [self.samples[i] for i in keep]
         self.rates = [self.rates[i] for i in keep]
-        if math.isinf(budget):
+        if math.isinf(budget) and mode != 'reference':
             budget = max(DEFAULT_BATCH_FRAMES, max(self.frames, default=0))
         self.batches = data.pack_batches(self.frames, budget, mode=mode)
         self.num_workers = max(int(num_workers), 1)

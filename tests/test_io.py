@@ -161,3 +161,25 @@ def test_wav_header_is_not_trusted(tmp_path):
     assert torch.load(out).shape == (40, 5) and not list(tmp_path.glob('*.tmp~'))
     with pytest.raises(ValueError):
         E.pt_write_batch([str(tmp_path / 'no_such_dir' / 'y.pt')], torch.zeros(1, 40, 5), [5], 1)
+
+
+def test_loader_reference_packing_mode(tmp_path, golden):
+    """PACKING_MODE 'reference': the file loader packs exactly like the reference
+    Sampler (fixture G8 sizes at max_frames 32000; one batch at infinity)."""
+    import ppgs_amd
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check of the loader')
+    g = golden('g8_packing')
+    lengths = g['lengths'][:40]
+    files = []
+    for i, frames in enumerate(lengths):
+        path = tmp_path / f'{i}.wav'
+        wavfile.write(path, 16000, np.zeros(int(frames) * 160, np.int16))
+        files.append(path)
+    from oracle import ppg_oracle as O
+    ref = O.sampler_batches(lengths, 32000)
+    loader = ppgs_amd.core.loader(files, num_workers=1, max_frames=32000, mode='reference')
+    assert [len(b) for b in loader.batches] == [len(b) for b in ref]
+    assert [list(b) for b in loader.batches] == [list(map(int, b)) for b in ref]
+    everything = ppgs_amd.core.loader(files, num_workers=1, max_frames=float('inf'), mode='reference')
+    assert len(everything.batches) == 1 and len(everything.batches[0]) == 40
