@@ -358,6 +358,7 @@ struct AttnArgs {
     const PpgWindow* win;
     int M;
     int ao_tiled;             // the output goes out in AO32 order (the layer32 kernel follows)
+    int heads;
 };
 
 struct GatherArgs {

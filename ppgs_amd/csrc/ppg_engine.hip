@@ -306,6 +306,14 @@ struct PpgEngine {
                         fprintf(stderr, "attn timing wave %d tile %d: dma-issue %llu  scores+softmax %llu  PV %llu  vmcnt %llu  barrier %llu | total %llu\n",
                                 w, c + 2, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
                     }
+            {   // per-workgroup records: start, end, valid keys, HW_ID -> PPGS_AMD_ATTN_TIMING_OUT (tools/attn_timeline.py)
+                std::vector<unsigned long long> rec(4096 * 4);
+                const char* path = getenv("PPGS_AMD_ATTN_TIMING_OUT");
+                if (path && hipMemcpy(rec.data(), attn_dbg + 64, rec.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                    FILE* f = fopen(path, "wb");
+                    if (f) { fwrite(rec.data(), 8, rec.size(), f); fclose(f); }
+                }
+            }
             (void)hipFree(attn_dbg);
         }
         if (lin_dbg) {
@@ -787,8 +795,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         HIP_OK(hipMemset(e->lin_dbg, 0, 16 * 8192 * 8));
     }
     if (getenv("PPGS_AMD_ATTN_TIMING")) {
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->attn_dbg), 512));
-        HIP_OK(hipMemset(e->attn_dbg, 0, 512));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->attn_dbg), 512 + 4096 * 32));
+        HIP_OK(hipMemset(e->attn_dbg, 0, 512 + 4096 * 32));
     }
     if (getenv("PPGS_AMD_FFN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 2048));
@@ -1053,7 +1061,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
-            a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32;
+            a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32; a.heads = c.heads;
             if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) if (atoi(v) & 8) a.ao_tiled = 0;
             a.dbg = l == 0 ? e->attn_dbg : nullptr;
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");

@@ -1407,9 +1407,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15;
     const int g = lane >> 4;
-    const AttnItem item = a.items[blockIdx.x];
+    // One launch index over (item, head), heads innermost: the items arrive longest first, and with a
+    // 2-D grid the whole first head (long AND short items) was dispatched before the second head's
+    // long items -- 64 of those then started 18 us into a 38 us launch (tools/attn_timeline.py).
+    const int item_index = blockIdx.x / a.heads;
+    const AttnItem item = a.items[item_index];
     const struct { int tok_off, vt_off, frames, valid; } w = {item.tok_off, item.vt_off, item.frames, item.valid};
-    const int head = blockIdx.y;
+#ifdef PPG_ATTN_TIMING
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole chip
+#endif
+    const int head = blockIdx.x - item_index * a.heads;
     const int qw0 = item.q0 + wave * 16 * NTQ;      // first query of this wave
 
     // Q fragments
@@ -1547,7 +1554,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 
 #ifdef PPG_ATTN_TIMING
     auto stamp = [&](int kt, int k) {
-        if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && kt >= 2 && kt < 4)
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && kt >= 2 && kt < 4)
             a.dbg[(wave * 2 + (kt - 2)) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
 #else
@@ -1613,6 +1620,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
                      oacc[db][t][2] * inv, oacc[db][t][3] * inv);
         }
     }
+#ifdef PPG_ATTN_TIMING
+    if (a.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* rec = a.dbg + 64 + 4 * (size_t)blockIdx.x;
+        rec[0] = wg_t0; rec[1] = __builtin_amdgcn_s_memrealtime(); rec[2] = (unsigned long long)w.valid;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        rec[3] = hwid;
+    }
+#endif
 }
 
 template <class P, int NT, int NB, int EPI>
@@ -1711,9 +1728,9 @@ hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
 template <class P>
 hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
     if (head_dim == 128) {
-        hipLaunchKernelGGL((attn_kernel<P, 2, 128>), dim3(nitems, heads), dim3(256), 65536, s, a);
+        hipLaunchKernelGGL((attn_kernel<P, 2, 128>), dim3(nitems * heads), dim3(256), 65536, s, a);
     } else if (head_dim == 256) {
-        hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems, heads), dim3(256), 65536, s, a);
+        hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems * heads), dim3(256), 65536, s, a);
     } else {
         return hipErrorInvalidValue;
     }
