@@ -210,6 +210,32 @@ int ppg_resample(int device, const float* audio, int batch, int64_t samples,
                  int orig_rate, int new_rate, float* out, void* stream);
 
 /*
+ * wav2vec 2.0 feature encoder of the 'w2v2fb' representation (reference
+ * ppgs/preprocess/w2v2fb/core.py:66 calls HF transformers
+ * Wav2Vec2Model.feature_extractor -- Wav2Vec2FeatureEncoder of
+ * models/wav2vec2/modeling_wav2vec2.py: Conv1d(1,512,k10,s5) + GroupNorm(512,512)
+ * + GELU, then six Conv1d(512,512,k{3,3,3,3,2,2},s2) + GELU, no biases).
+ *   weights : host fp32 arrays in torch layout: conv_weight[l] (512, Cin, k),
+ *             norm_weight / norm_bias (512) of layer 0's GroupNorm
+ *   audio   : device fp32 (batch, samples), already padded as the caller wants
+ *   out     : device fp32 (batch, ppg_w2v2_frames(samples), 512) = HF's
+ *             extract_features before the feature projection
+ * The layers run as MFMA GEMMs in the precision given at creation.
+ */
+typedef struct PpgW2v2Weights {
+    const float* conv_weight[7];
+    const float* norm_weight;
+    const float* norm_bias;
+} PpgW2v2Weights;
+typedef struct PpgW2v2 PpgW2v2;
+int ppg_w2v2_create(const PpgW2v2Weights* weights, int precision, int device, PpgW2v2** out);
+void ppg_w2v2_destroy(PpgW2v2* model);
+int64_t ppg_w2v2_frames(int64_t samples);
+int ppg_w2v2_workspace_bytes(const PpgW2v2* model, int batch, int64_t samples, size_t* bytes);
+int ppg_w2v2_features(PpgW2v2* model, const float* audio, int batch, int64_t samples, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * PPG post-ops on the device (per-frame arithmetic over the 40 phonemes).
  *
  * ppg_distance: replaces the body of ppgs.distance (ppgs/core.py:399-472).

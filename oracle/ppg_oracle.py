@@ -399,3 +399,32 @@ def grid_sample(ppg, grid):
     upper = torch.where(grid < 0, torch.zeros_like(low), low + 1).clamp(max=frames).long()
     extended = torch.cat([ppg, ppg[..., -1:]], dim=-1)          # final frame replicated
     return (1. - weight) * extended[..., upper - 1] + weight * extended[..., upper]
+
+
+###############################################################################
+# wav2vec 2.0 feature encoder (w2v2fb representation)
+###############################################################################
+
+
+W2V2_KERNELS = (10, 3, 3, 3, 3, 2, 2)      # transformers Wav2Vec2Config().conv_kernel (transformers 5.15.0 here)
+W2V2_STRIDES = (5, 2, 2, 2, 2, 2, 2)       # .conv_stride
+
+
+def w2v2_feature_encoder(state, audio):
+    """HF transformers ``Wav2Vec2FeatureEncoder.forward`` restated (the third-party
+    body reference ppgs/preprocess/w2v2fb/core.py:66 runs; models/wav2vec2/
+    modeling_wav2vec2.py: Wav2Vec2GroupNormConvLayer for layer 0 -- Conv1d without
+    bias, GroupNorm(512 groups, 512 channels, eps 1e-5, affine), GELU -- and
+    Wav2Vec2NoLayerNormConvLayer for layers 1..6 -- Conv1d without bias, GELU):
+    audio (B, N) fp32 -> extract_features (B, frames, 512) fp32.  `state` = the
+    feature_extractor's state dict.  Pinned by tests/golden/g11_w2v2_features.npz,
+    the output of the HF module itself (oracle/make_golden_w2v2.py)."""
+    x = audio[:, None].to(torch.float)
+    for layer, stride in enumerate(W2V2_STRIDES):
+        x = torch.nn.functional.conv1d(x, state[f'conv_layers.{layer}.conv.weight'], None, stride=stride)
+        if layer == 0:
+            x = torch.nn.functional.group_norm(
+                x, x.shape[1], state['conv_layers.0.layer_norm.weight'],
+                state['conv_layers.0.layer_norm.bias'], 1e-5)
+        x = torch.nn.functional.gelu(x)
+    return x.transpose(1, 2)

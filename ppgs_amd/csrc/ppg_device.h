@@ -222,6 +222,7 @@ enum {
     EPI_RESLN = 2,    // +bias +residual, LayerNorm -> X [+ Xb]
     EPI_RELU = 3,     // +bias, ReLU -> hidden (unfused FFN path)
     EPI_OUTCONV = 4,  // +bias, mask, softmax over 40, scatter into (B,40,T)
+    EPI_GELU = 5,     // strided k-tap conv without bias + exact GELU -> out_rows (wav2vec2 feature encoder layers 1..6)
 };
 
 struct LinearArgs {
@@ -255,6 +256,8 @@ struct LinearArgs {
     int M;                    // rows in the token-major buffers (multiple of 16)
     unsigned long long* dbg;  // PPG_LIN_TIMING builds: 16 s_memtime stamps per workgroup (tools/lin_timing.py)
     int x_tiled;              // EPI_INCONV: X is written in X32 order (the layer32 kernel follows)
+    int stride;               // EPI_GELU: output row m reads input rows stride * m + tap, tap = 0 .. taps - 1
+    int M_in;                 // EPI_GELU: rows of the input buffer
 };
 
 struct FfnArgs {

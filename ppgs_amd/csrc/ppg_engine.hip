@@ -1153,6 +1153,142 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     return PPG_OK;
 }
 
+// ----------------------------------------------------------------------------
+// wav2vec 2.0 feature encoder (w2v2fb representation)
+// ----------------------------------------------------------------------------
+namespace {
+constexpr int kW2vLayers = 7;
+const int kW2vKernel[kW2vLayers] = {10, 3, 3, 3, 3, 2, 2};      // transformers Wav2Vec2Config.conv_kernel
+const int kW2vStride[kW2vLayers] = {5, 2, 2, 2, 2, 2, 2};       // .conv_stride
+constexpr int kW2vChannels = 512;
+
+// frames after each layer and the padded rows per item of each layer's token-major buffer:
+// R[l-1] = 2 R[l], so that row m of layer l reads rows 2m + tap of layer l-1 for EVERY item
+// (item b starts at row b * R[l]); R[6] = T[6] + 1 rounded up to 32 keeps every row a valid
+// output reads inside its own item
+struct W2vShape { long T[kW2vLayers]; long R[kW2vLayers]; };
+bool w2v_shape(long samples, W2vShape* sh) {
+    long t = samples;
+    for (int l = 0; l < kW2vLayers; ++l) {
+        if (t < kW2vKernel[l]) return false;
+        t = (t - kW2vKernel[l]) / kW2vStride[l] + 1;
+        sh->T[l] = t;
+    }
+    sh->R[kW2vLayers - 1] = (sh->T[kW2vLayers - 1] + 1 + 31) / 32 * 32;
+    for (int l = kW2vLayers - 2; l >= 0; --l) sh->R[l] = 2 * sh->R[l + 1];
+    return true;
+}
+}  // namespace
+
+struct PpgW2v2 {
+    PpgEngine eng;                 // device, operand size, upload bookkeeping
+    float* w0 = nullptr;           // (512, 10)
+    float* gamma = nullptr;
+    float* beta = nullptr;
+    char* w[kW2vLayers] = {};      // layers 1..6: [512 rows in paired order][taps * 512], GEMM operand type
+};
+
+int ppg_w2v2_create(const PpgW2v2Weights* wts, int precision, int device, PpgW2v2** out) {
+    if (!wts || !out) return fail(PPG_EINVAL, "null argument");
+    if (precision != PPG_PRECISION_FP32 && precision != PPG_PRECISION_BF16 && precision != PPG_PRECISION_FP16)
+        return fail(PPG_EINVAL, "precision %d", precision);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PPG_EDEVICE, "no HIP device: the wav2vec2 feature encoder has no CPU path");
+    if (device < 0 || device >= ndev) return fail(PPG_EDEVICE, "device %d of %d", device, ndev);
+    HIP_OK(hipSetDevice(device));
+    std::unique_ptr<PpgW2v2> m(new PpgW2v2());
+    PpgEngine* E = &m->eng;
+    E->device = device;
+    E->cfg.precision = precision;
+    E->sz = precision == PPG_PRECISION_FP32 ? 4 : 2;
+    E->KG = 64 / E->sz;
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    E->num_cus = prop.multiProcessorCount;
+    int rc;
+    for (int l = 0; l < kW2vLayers; ++l) if (!wts->conv_weight[l]) return fail(PPG_EINVAL, "conv_weight[%d] is null", l);
+    if (!wts->norm_weight || !wts->norm_bias) return fail(PPG_EINVAL, "group-norm parameters are null");
+    if ((rc = upload_f32(E, wts->conv_weight[0], (size_t)kW2vChannels * 10, 0, &m->w0))) return rc;
+    if ((rc = upload_f32(E, wts->norm_weight, kW2vChannels, 0, &m->gamma))) return rc;
+    if ((rc = upload_f32(E, wts->norm_bias, kW2vChannels, 0, &m->beta))) return rc;
+    for (int l = 1; l < kW2vLayers; ++l) {
+        // torch Conv1d weight (out, in, k) -> [out (paired order)][tap * 512 + in]
+        const float* w = wts->conv_weight[l];
+        const int k = kW2vKernel[l], C = kW2vChannels;
+        rc = upload_matrix(E, C, k * C, C, k * C,
+                           [&](int r, int col) { const int tap = col / C, c = col - tap * C; return w[((size_t)pair_row(r) * C + c) * k + tap]; },
+                           &m->w[l]);
+        if (rc) return rc;
+    }
+    *out = m.release();
+    return PPG_OK;
+}
+
+void ppg_w2v2_destroy(PpgW2v2* model) { delete model; }
+
+int64_t ppg_w2v2_frames(int64_t samples) {
+    W2vShape sh;
+    return w2v_shape(samples, &sh) ? sh.T[kW2vLayers - 1] : -1;
+}
+
+int ppg_w2v2_workspace_bytes(const PpgW2v2* model, int batch, int64_t samples, size_t* bytes) {
+    if (!model || !bytes || batch <= 0) return fail(PPG_EINVAL, "bad argument");
+    W2vShape sh;
+    if (!w2v_shape(samples, &sh)) return fail(PPG_EINVAL, "%lld samples are too few for the conv stack", (long long)samples);
+    const size_t row = (size_t)kW2vChannels * model->eng.sz;
+    size_t total = align_up((size_t)batch * 65 * sizeof(double), 256);
+    total += align_up((size_t)batch * kW2vChannels * sizeof(float2), 256);
+    total += align_up((size_t)batch * sh.R[0] * row, 256);
+    total += align_up((size_t)batch * sh.R[1] * row, 256);
+    *bytes = total;
+    return PPG_OK;
+}
+
+int ppg_w2v2_features(PpgW2v2* model, const float* audio, int batch, int64_t samples, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!model || !audio || !out || !workspace) return fail(PPG_EINVAL, "null argument");
+    size_t need = 0;
+    int rc = ppg_w2v2_workspace_bytes(model, batch, samples, &need);
+    if (rc) return rc;
+    if (workspace_bytes < need) return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, need);
+    PpgEngine* E = &model->eng;
+    HIP_OK(hipSetDevice(E->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    W2vShape sh;
+    w2v_shape(samples, &sh);
+    const size_t row = (size_t)kW2vChannels * E->sz;
+    char* base = static_cast<char*>(workspace);
+    double* moments = reinterpret_cast<double*>(base);
+    size_t off = align_up((size_t)batch * 65 * sizeof(double), 256);
+    float2* scale_shift = reinterpret_cast<float2*>(base + off);
+    off += align_up((size_t)batch * kW2vChannels * sizeof(float2), 256);
+    char* bufs[2];
+    bufs[0] = base + off;
+    off += align_up((size_t)batch * sh.R[0] * row, 256);
+    bufs[1] = base + off;
+    const int prec = E->cfg.precision;
+    hipError_t he = ppg::launch_w2v2_layer0(prec, audio, batch, samples, sh.T[0], (int)sh.R[0], model->w0, model->gamma, model->beta,
+                                            moments, scale_shift, bufs[0], s);
+    if (he != hipSuccess) return fail(PPG_EDEVICE, "w2v2 layer 0: %s", hipGetErrorString(he));
+    for (int l = 1; l < kW2vLayers; ++l) {
+        LinearArgs a{};
+        a.v_start = INT_MAX;
+        a.act = bufs[(l - 1) & 1]; a.lda_bytes = (int)row; a.taps = kW2vKernel[l];
+        a.groups_per_tap = kW2vChannels / E->KG;
+        a.real_groups = a.total_groups = a.taps * a.groups_per_tap;
+        a.W = model->w[l]; a.N = kW2vChannels; a.H = kW2vChannels;
+        a.out_rows = bufs[l & 1]; a.out_ld = kW2vChannels;
+        a.M = (int)(batch * sh.R[l]); a.M_in = (int)(batch * sh.R[l - 1]); a.stride = kW2vStride[l];
+        const int nt = choose_nt(E, a.M, E->sz == 2 ? 2 : 2);
+        he = ppg::launch_linear(prec, EPI_GELU, 16, std::min(nt, 2), a, kW2vChannels / 256, s);
+        if (he != hipSuccess) return fail(PPG_EDEVICE, "w2v2 conv layer %d: %s", l, hipGetErrorString(he));
+    }
+    he = ppg::launch_w2v2_output(prec, bufs[(kW2vLayers - 1) & 1], batch, (int)sh.R[kW2vLayers - 1], sh.T[kW2vLayers - 1], out, s);
+    if (he != hipSuccess) return fail(PPG_EDEVICE, "w2v2 output: %s", hipGetErrorString(he));
+    return PPG_OK;
+}
+
 int ppg_frontend(int device, const float* audio, int batch, int samples, void* spec, void* mel, void* stream) {
     if (!audio || (!spec && !mel)) return fail(PPG_EINVAL, "null argument");
     if (batch <= 0) return fail(PPG_EINVAL, "batch %d", batch);

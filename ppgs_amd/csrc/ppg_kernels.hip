@@ -570,7 +570,12 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if constexpr (CONV) {
+                if constexpr (EPI == EPI_GELU) {
+                    const int m = tok0 + 16 * t + idx;
+                    const int mi = a.stride * m + tap;
+                    if (m < a.M && mi < a.M_in && gk < a.real_groups)
+                        v = *reinterpret_cast<const u32x4*>(a.act + (size_t)mi * a.lda_bytes + kgi * 64 + g * 16);
+                } else if constexpr (CONV) {
                     const int st = tm[t].tt + tap - pad;
                     if (tm[t].w >= 0 && gk < a.real_groups && st >= 0 && st < tm[t].frames) {
                         const int m = tok0 + 16 * t + idx + tap - pad;
@@ -729,6 +734,21 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                     }
                 }
                 done_with_previous = paired;
+            }
+        }
+    } else if constexpr (EPI == EPI_GELU) {
+        // exact GELU (erf form, torch.nn.functional.gelu default); W rows in paired order: 16-byte stores
+        PairStore<P> pair[NT];
+        auto gelu = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); };
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + pair_feature(nb, g);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int m = tok0 + 16 * t + idx;
+                if (m >= a.M) continue;
+                pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
+                            gelu(acc[nb][t][0]), gelu(acc[nb][t][1]), gelu(acc[nb][t][2]), gelu(acc[nb][t][3]));
             }
         }
     } else if constexpr (EPI == EPI_RELU) {
@@ -1659,6 +1679,7 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
     case EPI_INCONV: return launch_linear_nt<P, 16, EPI_INCONV>(nt, a, ypasses, s);
     case EPI_QKV:    return launch_linear_nt<P, 16, EPI_QKV>(nt, a, ypasses, s);
     case EPI_RELU:   return launch_linear_nt<P, 16, EPI_RELU>(nt, a, ypasses, s);
+    case EPI_GELU:   return launch_linear_nt<P, 16, EPI_GELU>(nt, a, ypasses, s);
     case EPI_OUTCONV:return launch_linear_nt<P, 3, EPI_OUTCONV>(nt, a, ypasses, s);
     case EPI_RESLN:
         // one 16-token block per wave: the LayerNorm epilogue holds a whole feature row per token in registers

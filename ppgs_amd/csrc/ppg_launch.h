@@ -22,6 +22,11 @@ hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, 
 // feature-split layer kernel (ppg_layer32.hip): 16-bit precisions, hidden 256, F a multiple of 128
 hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s);
 constexpr int kLayer32Tokens = 160;   // token rows per workgroup
+// wav2vec2 feature encoder, layer 0 (conv k10 s5 + GroupNorm + GELU; ppg_w2v2.hip) and the fp32 read-out of the last layer
+hipError_t launch_w2v2_layer0(int precision, const float* audio, int batch, long samples, long frames, int rows_per_item,
+                              const float* w0, const float* gamma, const float* beta, double* moments, float2* scale_shift,
+                              char* out, hipStream_t s);
+hipError_t launch_w2v2_output(int precision, const char* rows, int batch, int rows_per_item, long frames, float* out, hipStream_t s);
 
 constexpr int kMaxMelWeights = 1536;   // LDS room for the packed filterbank (1001 non-zeros + interior zeros)
 

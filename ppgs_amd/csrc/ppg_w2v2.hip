@@ -1,0 +1,174 @@
+// wav2vec 2.0 feature encoder, first layer (reference
+// ppgs/preprocess/w2v2fb/core.py:66 -> HF transformers Wav2Vec2FeatureEncoder,
+// modeling_wav2vec2.py: Wav2Vec2GroupNormConvLayer = Conv1d(1, 512, k 10, s 5, no
+// bias) -> GroupNorm(512 groups of 1 channel, eps 1e-5, affine) -> GELU):
+//
+//   y0[b][t][c] = gelu(a[b][c] * sum_j w[c][j] x[b][5t + j] + s[b][c])
+//
+// The GroupNorm statistics of channel c run over all frames of the (padded) row.
+// The convolution is linear, so they follow from 65 moments of the audio alone --
+// M1[j] = sum_t x[5t+j], M2[j][k] = sum_t x[5t+j] x[5t+k] -- accumulated in fp64:
+// mean_c = w_c . M1 / T, E[y^2] = w_c' M2 w_c / T.  No pass over the 512-channel
+// activation is needed for them, and the normalised, activated layer-0 output is
+// written exactly once, token-major [batch * R0][512] in the GEMM operand type:
+// what layers 1..6 (linear_kernel<EPI_GELU>: strided 3- / 2-tap convolutions as
+// MFMA GEMMs) read as their B operand.
+#include "ppg_device.h"
+#include "ppg_launch.h"
+
+namespace {
+
+constexpr int W2V_C = 512;
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// moments[b][0..9] = M1, [10..64] = upper triangle of M2 (j <= k, row-major)
+__global__ __launch_bounds__(256) void w2v2_moments_kernel(const float* audio, long samples, long frames, double* moments) {
+    const int b = blockIdx.y;
+    const float* x = audio + (size_t)b * samples;
+    double acc[65];
+#pragma unroll
+    for (int i = 0; i < 65; ++i) acc[i] = 0.0;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < frames; t += (long)gridDim.x * 256) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * t + j];
+        int o = 10;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            acc[j] += v[j];
+#pragma unroll
+            for (int k = j; k < 10; ++k) acc[o++] += (double)v[j] * (double)v[k];
+        }
+    }
+    __shared__ double red[4][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 65; ++i) {
+        double v = acc[i];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 65)
+        atomicAdd(moments + (size_t)b * 65 + threadIdx.x,
+                  (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// scale_shift[b][c] = (a, s): gelu argument = a * conv + s
+__global__ __launch_bounds__(256) void w2v2_norm_kernel(const double* moments, const float* w0, const float* gamma, const float* beta,
+                                                        long frames, float2* scale_shift) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= W2V_C) return;
+    const double* m = moments + (size_t)b * 65;
+    double w[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w[j] = w0[c * 10 + j];
+    double mean = 0.0, ey2 = 0.0;
+    int o = 10;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        mean += w[j] * m[j];
+#pragma unroll
+        for (int k = j; k < 10; ++k) ey2 += (j == k ? 1.0 : 2.0) * w[j] * w[k] * m[o++];
+    }
+    mean /= (double)frames;
+    ey2 /= (double)frames;
+    const double var = fmax(ey2 - mean * mean, 0.0);
+    const double a = (double)gamma[c] / sqrt(var + 1e-5);
+    scale_shift[(size_t)b * W2V_C + c] = make_float2((float)a, (float)((double)beta[c] - mean * a));
+}
+
+// 64 frames x 512 channels per workgroup; thread = 2 channels, all 64 frames
+template <class P>
+__global__ __launch_bounds__(256) void w2v2_conv0_kernel(const float* audio, long samples, long frames, int rows_per_item,
+                                                         const float* w0, const float2* scale_shift, char* out) {
+    __shared__ float win[64 * 5 + 16];
+    const int b = blockIdx.y;
+    const long t0 = (long)blockIdx.x * 64;
+    const float* x = audio + (size_t)b * samples;
+    for (int i = threadIdx.x; i < 64 * 5 + 5; i += 256) {
+        const long n = 5 * t0 + i;
+        win[i] = n < samples ? x[n] : 0.f;
+    }
+    const int c = 2 * threadIdx.x;
+    float w[2][10];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[e][j] = w0[(c + e) * 10 + j];
+    const float2 ss0 = scale_shift[(size_t)b * W2V_C + c], ss1 = scale_shift[(size_t)b * W2V_C + c + 1];
+    __syncthreads();
+    typename P::elem* dst = reinterpret_cast<typename P::elem*>(out) + ((size_t)b * rows_per_item + t0) * W2V_C + c;
+    for (int t = 0; t < 64; ++t) {
+        float y0 = 0.f, y1 = 0.f;
+        if (t0 + t < frames) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float v = win[5 * t + j];
+                y0 = fmaf(w[0][j], v, y0);
+                y1 = fmaf(w[1][j], v, y1);
+            }
+            y0 = gelu_exact(fmaf(ss0.x, y0, ss0.y));
+            y1 = gelu_exact(fmaf(ss1.x, y1, ss1.y));
+        }
+        if (t0 + t < rows_per_item) {
+            if constexpr (P::kIsBF16) *reinterpret_cast<uint32_t*>(dst + (size_t)t * W2V_C) = P::pack2(y0, y1);
+            else *reinterpret_cast<float2*>(dst + (size_t)t * W2V_C) = make_float2(y0, y1);
+        }
+    }
+}
+
+// rows t < frames of every item, as fp32 (batch, frames, 512)
+template <class P>
+__global__ __launch_bounds__(256) void w2v2_output_kernel(const char* rows, int rows_per_item, long frames, float* out) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;        // float4 index inside the item
+    if (i >= frames * (W2V_C / 4)) return;
+    const long t = i / (W2V_C / 4);
+    const int c = (int)(i - t * (W2V_C / 4)) * 4;
+    const typename P::elem* src = reinterpret_cast<const typename P::elem*>(rows) + ((size_t)b * rows_per_item + t) * W2V_C + c;
+    float4 v;
+    if constexpr (std::is_same_v<P, PrecF32>) {
+        v = *reinterpret_cast<const float4*>(src);
+    } else {
+        const uint2 raw = *reinterpret_cast<const uint2*>(src);
+        if constexpr (std::is_same_v<P, PrecBF16>) {
+            v = make_float4(bf16_to_f32((uint16_t)raw.x), bf16_to_f32((uint16_t)(raw.x >> 16)),
+                            bf16_to_f32((uint16_t)raw.y), bf16_to_f32((uint16_t)(raw.y >> 16)));
+        } else {
+            v = make_float4((float)__builtin_bit_cast(_Float16, (uint16_t)raw.x), (float)__builtin_bit_cast(_Float16, (uint16_t)(raw.x >> 16)),
+                            (float)__builtin_bit_cast(_Float16, (uint16_t)raw.y), (float)__builtin_bit_cast(_Float16, (uint16_t)(raw.y >> 16)));
+        }
+    }
+    *reinterpret_cast<float4*>(out + ((size_t)b * frames + t) * W2V_C + c) = v;
+}
+
+}  // namespace
+
+namespace ppg {
+
+hipError_t launch_w2v2_layer0(int precision, const float* audio, int batch, long samples, long frames, int rows_per_item,
+                              const float* w0, const float* gamma, const float* beta, double* moments, float2* scale_shift,
+                              char* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(moments, 0, (size_t)batch * 65 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    const int mblocks = (int)std::min<long>((frames + 2047) / 2048, 256);
+    hipLaunchKernelGGL(w2v2_moments_kernel, dim3(std::max(mblocks, 1), batch), dim3(256), 0, s, audio, samples, frames, moments);
+    hipLaunchKernelGGL(w2v2_norm_kernel, dim3(W2V_C / 256, batch), dim3(256), 0, s, moments, w0, gamma, beta, frames, scale_shift);
+    const dim3 grid((rows_per_item + 63) / 64, batch);
+    if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(w2v2_conv0_kernel<PrecBF16>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
+    else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(w2v2_conv0_kernel<PrecF16>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
+    else hipLaunchKernelGGL(w2v2_conv0_kernel<PrecF32>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_w2v2_output(int precision, const char* rows, int batch, int rows_per_item, long frames, float* out, hipStream_t s) {
+    const dim3 grid((unsigned)((frames * (W2V_C / 4) + 255) / 256), batch);
+    if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(w2v2_output_kernel<PrecBF16>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
+    else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(w2v2_output_kernel<PrecF16>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
+    else hipLaunchKernelGGL(w2v2_output_kernel<PrecF32>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
+    return hipGetLastError();
+}
+
+}  // namespace ppg

@@ -97,6 +97,15 @@ SYMBOLS = {
     'ppg_grid_sample': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_w2v2_create': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'ppg_w2v2_destroy': (None, [ctypes.c_void_p]),
+    'ppg_w2v2_frames': (ctypes.c_int64, [ctypes.c_int64]),
+    'ppg_w2v2_workspace_bytes': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]),
+    'ppg_w2v2_features': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'ppg_engine_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'ppg_engine_profile_read': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
@@ -472,6 +481,78 @@ def grid_sample(ppg, grid):
                 x.device.index, x.data_ptr(), rows, x.shape[-1], g.data_ptr(),
                 g.shape[0], out.data_ptr(), torch.cuda.current_stream().cuda_stream))
     return out      # fp32 also for half-precision PPGs: the reference's float grid promotes them
+
+
+class PpgW2v2Weights(ctypes.Structure):
+    _fields_ = [('conv_weight', _FP * 7), ('norm_weight', _FP), ('norm_bias', _FP)]
+
+
+class W2v2FeatureEncoder:
+    """The wav2vec 2.0 convolutional feature encoder on the HIP engine
+    (ppg_w2v2_*): HF ``Wav2Vec2Model.feature_extractor`` -- seven strided
+    convolutions, GroupNorm on the first, exact GELU -- from its state dict
+    (keys ``conv_layers.{l}.conv.weight``, ``conv_layers.0.layer_norm.*``)."""
+
+    def __init__(self, state, device=0, precision='fp16'):
+        if not torch.cuda.is_available():
+            raise PpgError(
+                'ppgs_amd: no HIP device visible; the engine has no CPU path')
+        lib = library()
+        keep = []
+
+        def ptr(key):
+            tensor = state[key].detach().to('cpu', torch.float32).contiguous()
+            keep.append(tensor)
+            return ctypes.cast(tensor.data_ptr(), _FP)
+        wts = PpgW2v2Weights()
+        for layer in range(7):
+            wts.conv_weight[layer] = ptr(f'conv_layers.{layer}.conv.weight')
+        wts.norm_weight = ptr('conv_layers.0.layer_norm.weight')
+        wts.norm_bias = ptr('conv_layers.0.layer_norm.bias')
+        expected = [(512, 1, 10)] + [(512, 512, 3)] * 4 + [(512, 512, 2)] * 2
+        shapes = [tuple(state[f'conv_layers.{i}.conv.weight'].shape) for i in range(7)]
+        if shapes != expected:
+            raise ValueError(f'not a wav2vec2-base feature encoder: conv weights {shapes}')
+        handle = ctypes.c_void_p()
+        _check(lib.ppg_w2v2_create(
+            ctypes.byref(wts), PRECISIONS[precision], device, ctypes.byref(handle)))
+        self._handle, self._lib = handle, lib
+        self.device = torch.device('cuda', device)
+        self.precision = precision
+        self._workspaces = {}
+
+    def __del__(self):
+        handle = getattr(self, '_handle', None)
+        if handle:
+            self._lib.ppg_w2v2_destroy(handle)
+            self._handle = None
+
+    def frames(self, samples):
+        return int(self._lib.ppg_w2v2_frames(int(samples)))
+
+    def __call__(self, audio):
+        """audio (batch, samples) fp32 on this GPU -> (batch, frames, 512) fp32
+        (HF ``extract_features`` before the feature projection)."""
+        if audio.dim() != 2:
+            raise ValueError(f'audio must be (batch, samples), got {tuple(audio.shape)}')
+        audio = audio.to(self.device, torch.float32).contiguous()
+        batch, samples = audio.shape
+        frames = self.frames(samples)
+        if frames < 1:
+            raise ValueError(f'{samples} samples are too few for the conv stack')
+        size = ctypes.c_size_t()
+        _check(self._lib.ppg_w2v2_workspace_bytes(self._handle, batch, samples, ctypes.byref(size)))
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            workspace = self._workspaces.get(stream)
+            if workspace is None or workspace.numel() < size.value:
+                workspace = torch.empty(size.value, dtype=torch.uint8, device=self.device)
+                self._workspaces[stream] = workspace
+            out = torch.empty((batch, frames, 512), dtype=torch.float32, device=self.device)
+            _check(self._lib.ppg_w2v2_features(
+                self._handle, audio.data_ptr(), batch, samples, out.data_ptr(),
+                workspace.data_ptr(), workspace.numel(), stream))
+        return out
 
 
 def frontend_profile(device, enable=True):

@@ -2,11 +2,14 @@
 ppgs/preprocess/w2v2fb/core.py:32-75.
 
 The reference delegates the body to the third-party HF ``Wav2Vec2Model``
-('facebook/wav2vec2-base'); so does this module for now -- on the HIP device
-through stock PyTorch-ROCm ops.  It is the boundary of the hot path for the
-w2v2fb configuration: everything after it -- the
-768-channel, hidden-512 PPG network -- runs in the hand-written HIP engine.
-A native HIP wav2vec2 body is the first "next" row.
+('facebook/wav2vec2-base').  Here the model's convolutional feature encoder
+(7 strided convolutions, GroupNorm, GELU: most of the audio-rate work) runs in
+the hand-written HIP engine (``engine.W2v2FeatureEncoder``, ppg_w2v2.hip +
+linear_kernel<EPI_GELU>); the feature projection and the 12-layer transformer
+still run as the HF modules on the HIP device through stock PyTorch-ROCm ops
+(in progress).  Everything after the latents -- the
+768-channel, hidden-512 PPG network -- runs in the HIP engine.
+PPGS_AMD_W2V2_NATIVE=0 runs the whole HF model through PyTorch-ROCm.
 
 Same arithmetic as the reference: zero-pad 40 samples each side, attention
 mask over the first ``length + 80`` samples, ``last_hidden_state`` (B, ~T/2,
@@ -24,6 +27,7 @@ WINDOW_SIZE = 400
 HOP_SIZE = 320
 
 _models = {}
+_encoders = {}
 
 
 def model_for(device):
@@ -45,6 +49,29 @@ def model_for(device):
     return _models[key]
 
 
+def feature_encoder_for(device, model):
+    """Cached HIP feature encoder holding `model`'s convolution weights."""
+    from .. import core, engine
+    key = (str(device), id(model), core.PRECISION)
+    if key not in _encoders:
+        _encoders[key] = engine.W2v2FeatureEncoder(
+            model.feature_extractor.state_dict(), device.index, core.PRECISION)
+    return _encoders[key]
+
+
+def last_hidden_state(model, padded, mask):
+    """HF ``Wav2Vec2Model.forward`` (modeling_wav2vec2.py) with the feature
+    encoder replaced by the HIP kernels: extract_features -> frame-rate
+    attention mask -> feature_projection -> encoder."""
+    if os.environ.get('PPGS_AMD_W2V2_NATIVE', '1') == '0':
+        return model(padded, mask).last_hidden_state
+    extract = feature_encoder_for(padded.device, model)(padded)
+    attention_mask = model._get_feature_vector_attention_mask(
+        extract.shape[1], mask, add_adapter=False)
+    hidden, _ = model.feature_projection(extract)
+    return model.encoder(hidden, attention_mask=attention_mask).last_hidden_state
+
+
 def from_audios(audio, lengths, sample_rate=None, gpu=None):
     """(batch, 1, samples) fp32 + sample lengths -> (batch, 768, samples // 160)
     fp16 on the GPU (reference w2v2fb/core.py:32-75)."""
@@ -63,7 +90,7 @@ def from_audios(audio, lengths, sample_rate=None, gpu=None):
         # reference mask_from_lengths(lengths, pad): arange(max + 2 pad) - 2 pad < len
         positions = torch.arange(int(lengths.max()) + 2 * pad) - 2 * pad
         mask = (positions[None] < lengths[:, None]).to(torch.long).to(device)
-        output = model(padded, mask).last_hidden_state.transpose(1, 2)
+        output = last_hidden_state(model, padded, mask).transpose(1, 2)
         upsampled = torch.nn.functional.interpolate(
             output, size=audio.shape[-1] // config.HOPSIZE, mode='nearest')
         return upsampled.to(torch.float16)

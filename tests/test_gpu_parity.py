@@ -732,3 +732,82 @@ def test_plan_cache_eviction_and_graph_replay():
         scratch = torch.empty(engine.workspace_bytes(3, 77, [77, 77, 77]), dtype=torch.uint8, device='cuda')
         with torch.cuda.graph(graph):
             engine.encode(fresh, [77, 77, 77], workspace=scratch)
+
+
+# ----------------------------------------- wav2vec2 feature encoder (f1) ----
+
+def _seeded_w2v2(golden):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    from oracle import make_golden_w2v2 as M
+    g = golden('g11_w2v2_features')
+    model = M.seeded_model(int(g['seed']))
+    if abs(M.weight_checksum(model.feature_extractor) - float(g['checksum'])) > 1e-6 * float(g['checksum']):
+        pytest.skip('this torch / transformers build seeds the HF model differently from the fixture')
+    return g, model
+
+
+def test_w2v2_feature_encoder_vs_hf_fixture(golden):
+    """ppg_w2v2_features (conv0 + GroupNorm-from-moments + GELU, then six strided convolutions as
+    MFMA GEMMs) against the output of HF's own Wav2Vec2FeatureEncoder (fixture G11): fp32 mode
+    1e-4 on activations of magnitude ~3; fp16 operands 2e-2; ragged zero-padded row included."""
+    g, model = _seeded_w2v2(golden)
+    state = model.feature_extractor.state_dict()
+    audio = t(g['audio']).cuda()
+    for precision, tol in (('fp32', 1e-4), ('fp16', 2e-2), ('bf16', 1.5e-1)):
+        encoder = E.W2v2FeatureEncoder(state, 0, precision)
+        assert encoder.frames(6000) == 18
+        out = encoder(audio)
+        torch.cuda.synchronize()
+        assert out.shape == (3, 18, 512)
+        assert np.abs(out.cpu().numpy() - g['features']).max() < tol, precision
+        # workspace contents must not matter
+        for workspace in encoder._workspaces.values():
+            workspace.fill_(255)
+        assert torch.equal(out, encoder(audio))
+    with pytest.raises(ValueError):
+        encoder(torch.zeros(1, 300).cuda())
+
+
+def test_w2v2fb_representation_native_vs_pytorch(golden, monkeypatch):
+    """The w2v2fb representation end to end (reference ppgs/preprocess/w2v2fb/core.py:32-75: pad 40,
+    sample mask, Wav2Vec2Model, nearest upsampling, fp16) with the HIP feature encoder against the
+    same HF model run entirely by PyTorch-ROCm, and against the fixture's last_hidden_state."""
+    g, model = _seeded_w2v2(golden)
+    from ppgs_amd.preprocess import w2v2fb
+    device = torch.device('cuda', 0)
+    model = model.to(device)
+    monkeypatch.setattr(w2v2fb, '_models', {str(device): model})
+    monkeypatch.setattr(ppgs_amd.core, 'PRECISION', 'fp32')
+    audio = t(g['audio'])[:, None].cuda()
+    lengths = torch.tensor([6000, 4100, 6000])
+    native = w2v2fb.from_audios(audio, lengths, gpu=0)
+    monkeypatch.setenv('PPGS_AMD_W2V2_NATIVE', '0')
+    stock = w2v2fb.from_audios(audio, lengths, gpu=0)
+    assert native.shape == stock.shape == (3, 768, 37) and native.dtype == torch.float16
+    assert (native.float() - stock.float()).abs().max() < 5e-3
+    # unpadded, unmasked input through the model = the fixture's last_hidden_state
+    monkeypatch.delenv('PPGS_AMD_W2V2_NATIVE')
+    with torch.no_grad():
+        extract = w2v2fb.feature_encoder_for(device, model)(t(g['audio']).cuda())
+        projected, _ = model.feature_projection(extract)
+        hidden = model.encoder(projected).last_hidden_state
+    assert np.abs(hidden.cpu().numpy() - g['last_hidden_state']).max() < 2e-3
+
+
+def test_w2v2_feature_encoder_c3_size(golden):
+    """configs[2] size: 16 x 160080 samples (10 s + the reference's 40 + 40 pad) -> 16 x 500 frames,
+    HIP feature encoder against HF's on the same GPU (PyTorch-ROCm fp32) on spot rows."""
+    g, model = _seeded_w2v2(golden)
+    gen = torch.Generator().manual_seed(3)
+    audio = (0.1 * torch.randn(16, 160080, generator=gen)).cuda()
+    encoder = E.W2v2FeatureEncoder(model.feature_extractor.state_dict(), 0, 'fp32')
+    out = encoder(audio)
+    assert out.shape == (16, 500, 512) and bool(torch.isfinite(out).all())
+    extractor = model.feature_extractor.cuda()
+    with torch.no_grad():
+        ref = extractor(audio[[0, 7, 15]]).transpose(1, 2)
+    assert (out[[0, 7, 15]] - ref).abs().max() < 2e-4
+    fast = E.W2v2FeatureEncoder(model.feature_extractor.state_dict(), 0, 'fp16')(audio)
+    assert (fast[[0, 7, 15]] - ref).abs().max() < 3e-2

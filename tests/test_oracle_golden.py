@@ -196,3 +196,19 @@ def test_g10_resample_closed_form(golden):
         ref = g[f'out_{rate}']
         assert out.shape == ref.shape
         assert np.abs(out - ref).max() < 2e-7, rate
+
+
+def test_g11_w2v2_feature_encoder_matches_hf(golden):
+    """The restatement of HF's Wav2Vec2FeatureEncoder against the module's own output
+    (fixture G11, seeded random weights of the base architecture rebuilt here)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    from oracle import make_golden_w2v2 as M
+    g = golden('g11_w2v2_features')
+    model = M.seeded_model(int(g['seed']))
+    assert abs(M.weight_checksum(model.feature_extractor) - float(g['checksum'])) < 1e-6 * float(g['checksum'])
+    state = model.feature_extractor.state_dict()
+    out = O.w2v2_feature_encoder(state, t(g['audio'])).numpy()
+    assert out.shape == g['features'].shape == (3, 18, 512)
+    assert np.abs(out - g['features']).max() < 1e-5
