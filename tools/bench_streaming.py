@@ -33,13 +33,15 @@ def timed(fn, steps):
 
 
 def main():
+    import json
     parser = argparse.ArgumentParser()
     parser.add_argument('--steps', type=int, default=200)
     parser.add_argument('--batch', type=int, default=64)
     parser.add_argument('--frames', type=int, default=160)
+    parser.add_argument('--precision', default='bf16')
     args = parser.parse_args()
     state = ppgs_amd.weights.seeded_state_dict(seed=1234)
-    model = E.Engine(state, 0, 'bf16', is_causal=True)
+    model = E.Engine(state, 0, args.precision, is_causal=True)
     generator = torch.Generator().manual_seed(1234)
     feats = torch.randn(
         args.batch, 80, args.frames, generator=generator).half().cuda()
@@ -47,10 +49,31 @@ def main():
     eager = timed(lambda: model.encode(feats, lengths), args.steps)
     run = model.graphed(args.batch, args.frames)
     graphed = timed(lambda: run(feats), args.steps)
+    model.profile(True)
+    for _ in range(5):
+        model.encode(feats, lengths)
+    torch.cuda.synchronize()
+    kernels = {n: v[0] / 5 for n, v in model.profile_read().items()}
+    launches = {n: v[1] / 5 for n, v in model.profile_read().items()}
     per_step = args.batch * args.frames
-    for name, seconds in (('eager', eager), ('hipGraph replay', graphed)):
-        print(f'{name}: {seconds * 1e6:.1f} us/step, {1 / seconds:.0f} steps/s, '
-              f'{per_step / seconds / 1e6:.2f} M frames/s')
+    # single 160-frame windows: 13 414 400 FLOP per frame + 5120 Tc^2 per window (causal
+    # attention computes about half of the Tc^2 term)
+    flops = args.batch * (13_414_400 * args.frames + 5120 * args.frames ** 2)
+    layer_flops = (4 * 256 * 2048 + 2 * 256 * 256 + 6 * 256 * 256 * 4 / 5) * per_step
+    layer_ms = kernels['ffn'] / max(launches['ffn'], 1)
+    peak = 157.3 if args.precision == 'fp32' else 2500.0
+    print(json.dumps({
+        'config': f'configs[4]: causal_transformer, streaming {args.frames}-frame chunks, batch = {args.batch}, 1 MI355X, '
+                  'one hipGraph replay per step (each chunk an independent forward, as in the reference)',
+        'dtype': args.precision,
+        'eager': {'us_per_step': eager * 1e6, 'steps_per_s': 1 / eager, 'frames_per_s': per_step / eager},
+        'hipgraph_replay': {'us_per_step': graphed * 1e6, 'steps_per_s': 1 / graphed, 'frames_per_s': per_step / graphed},
+        'end_to_end_tflops': flops / graphed / 1e12,
+        'kernel_ms_per_step': kernels,
+        'roofline': {'kernel': 'layer kernel launches (10 240 token rows: token-split, hidden chunks split over workgroups)',
+                     'bound': 'mfma', 'achieved': layer_flops / layer_ms / 1e9, 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': layer_flops / layer_ms / 1e9 / peak, 'mean_launch_ms': layer_ms},
+    }))
 
 
 if __name__ == '__main__':
