@@ -297,14 +297,17 @@ struct FfnArgs {
 //    residual load and every LayerNorm store is one contiguous KiB per wave instruction;
 //  * AO32: the attention output as the kernel's B fragments (token panel: [tile][5 token blocks]
 //    [16 K-steps] fragments of 1 KiB, slot 8 (l >> 5) + j of K-step ks = feature 16 ks + 8 (l >> 5) + j).
-__host__ __device__ inline size_t x32_index(int m, int n) {        // float index of X[m][n], n % 4 == 0
-    const int tile = m / 160, r = m - tile * 160, tb = r >> 5, tok = r & 31;
-    const int w = n >> 6, rb = (n >> 5) & 1, hh = (n >> 4) & 1, q = (n >> 2) & 3;
-    return ((((((size_t)tile * 4 + w) * 5 + tb) * 2 + rb) * 4 + q) * 64 + hh * 32 + tok) * 4 + (n & 3);
+__host__ __device__ inline int layer32_tile_tokens(int hidden) { return hidden == 512 ? 96 : 160; }
+__host__ __device__ inline size_t x32_index(int m, int n, int hidden) {        // float index of X[m][n], n % 4 == 0
+    const int toks = layer32_tile_tokens(hidden), RB = hidden / 128, TB = toks / 32;
+    const int tile = m / toks, r = m - tile * toks, tb = r >> 5, tok = r & 31;
+    const int w = n / (32 * RB), rb = (n >> 5) % RB, hh = (n >> 4) & 1, q = (n >> 2) & 3;
+    return ((((((size_t)tile * 4 + w) * TB + tb) * RB + rb) * 4 + q) * 64 + hh * 32 + tok) * 4 + (n & 3);
 }
-__host__ __device__ inline size_t ao32_byte(int m, int n) {        // byte offset of AO[m][n], n % 8 == 0, 16-bit elements
-    const int tile = m / 160, r = m - tile * 160, tb = r >> 5, tok = r & 31;
-    return ((((size_t)tile * 5 + tb) * 16 + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + tok) * 16;
+__host__ __device__ inline size_t ao32_byte(int m, int n, int hidden) {        // byte offset of AO[m][n], n % 8 == 0, 16-bit elements
+    const int toks = layer32_tile_tokens(hidden), KS = hidden / 16, TB = toks / 32;
+    const int tile = m / toks, r = m - tile * toks, tb = r >> 5, tok = r & 31;
+    return ((((size_t)tile * TB + tb) * KS + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + tok) * 16;
 }
 
 // The feature-split layer kernel (ppg_layer32.hip): out-projection + residual + LayerNorm-1,
@@ -313,17 +316,18 @@ __host__ __device__ inline size_t ao32_byte(int m, int n) {        // byte offse
 // fragment, in consumption order; ppg_engine.hip pack_layer32).
 struct Layer32Args {
     const char* ao;           // attention output in AO32 order (see ao32_byte)
-    const char* wo_img;       // [4 waves][2 row blocks][16 k-steps] fragments
-    const char* w1_img;       // [F/128 chunks][4 waves][16 k-steps] fragments
-    const char* w2_img;       // [F/128 chunks][4 waves][2 row blocks][8 k-steps] fragments
+    const char* wo_img;       // [4 waves][RB row blocks][H/16 k-steps] fragments, RB = H/128
+    const char* w1_img;       // [F/128 chunks][4 waves][H/16 k-steps] fragments
+    const char* w2_img;       // [F/128 chunks][4 waves][RB row blocks][8 k-steps] fragments
     const float* bo; const float* g1; const float* e1;      // out-proj bias, norm1
     const float* b1; const float* b2; const float* g2; const float* e2;
     float* X;                 // residual stream fp32 in X32 order (see x32_index), in/out
     char* Xb;                 // row-major 16-bit copy of the result (operand of the kernels that follow); null: not written
     int M;
     int F;
+    int H;                    // 256 (160-token workgroups) or 512 (96-token workgroups)
     // fused Q/K/V projection of the next layer (wq_img != null)
-    const char* wq_img;       // [4 waves][6 row blocks][16 k-steps] fragments
+    const char* wq_img;       // [4 waves][3 RB steps][H/16 k-steps] fragments
     const float* bq;
     char* qk_out;             // [M][2H] (q | k)
     char* vt_out;             // transposed V [H][vt_ld]
@@ -332,6 +336,7 @@ struct Layer32Args {
     const PpgWindow* win;
     unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
     int debug_mode;           // PPGS_AMD_L32_DEBUG (bisecting): bit 0 skip the out-projection, bit 1 skip the FFN
+    int write_x;              // 0: the fp32 result is not stored (last layer: only the 16-bit copy is read afterwards)
 };
 
 // One attention workgroup's work: a query tile of one window.  The window fields

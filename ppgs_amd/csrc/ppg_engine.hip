@@ -433,7 +433,8 @@ Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
     w.qk_rows = (int)M + 64;
     w.vt_ld = vt_tokens + 64;
     w.xw = take(M * e->Cp * e->sz);
-    const size_t Mt = (M + 159) / 160 * 160;            // whole 160-token tiles (X32 / AO32 layouts of the layer32 kernel)
+    const size_t Ttile = layer32_tile_tokens(H);        // whole tiles of the layer32 kernel (X32 / AO32 layouts)
+    const size_t Mt = (M + Ttile - 1) / Ttile * Ttile;
     w.x = take(Mt * H * 4);
     w.xb = take(e->sz == 2 ? M * H * 2 : 0);
     w.qk = take((size_t)w.qk_rows * 2 * H * e->sz);
@@ -788,7 +789,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_FFN_SPLIT_MAX")) e->ffn_split_max = atoi(v);
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
-    if (e->sz != 2 || H != 256 || F % 128 || F > 6656) e->layer32 = false;
+    if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->lin_dbg), 16 * 8192 * 8));
@@ -873,43 +874,46 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         }
         if (e->layer32) {
             // Fragment images (ppg_layer32.hip): fragment = 64 lanes x 8 elements, lane l = (row l & 31 of
-            // the 32-row block, K slots 8 (l >> 5) .. +7 of the 16-wide K-step).  Output rows of a
-            // block sit in the order phi the accumulator layout hands a lane 16 consecutive features
-            // in; where a GEMM's K is the previous accumulator (x1, h, x2) the K order follows it.
+            // the 32-row block, K slots 8 (l >> 5) .. +7 of the 16-wide K-step).  Wave w owns features
+            // 32 RB w .. of a H-wide result (RB = H / 128).  Output rows of a block sit in the order phi
+            // the accumulator layout hands a lane 16 consecutive features in; where a GEMM's K is the
+            // previous accumulator (x1, h, x2) the K order follows it.
+            const int RB = H / 128, KS = H / 16;
             auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+            auto panel_k = [](int ks, int ln, int j) { return 32 * (ks >> 1) + 16 * (ln >> 5) + 8 * (ks & 1) + j; };   // feature in slot j of K-step ks
             auto image = [&](int frags, auto get, char** dst) {          // get(frag, lane, j)
                 return upload_matrix(E, frags * 64, 8, frags * 64, 8,
                                      [&](int r, int j) { return get(r >> 6, r & 63, j); }, dst);
             };
             const float* wo = wts->out_proj_weight[l];
-            rc = image(4 * 2 * 16, [&](int f, int ln, int j) {
-                const int ks = f & 15, rb = (f >> 4) & 1, w = f >> 5;
-                return wo[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * H + 16 * ks + 8 * (ln >> 5) + j];
+            rc = image(4 * RB * KS, [&](int f, int ln, int j) {          // [w][rb][ks], natural K (the attention output's)
+                const int ks = f % KS, rb = (f / KS) % RB, w = f / (KS * RB);
+                return wo[(size_t)(32 * RB * w + 32 * rb + phi(ln & 31)) * H + 16 * ks + 8 * (ln >> 5) + j];
             }, &d.wo_img);
             if (rc) return rc;
             const float* w1 = wts->linear1_weight[l];
-            rc = image(F / 128 * 4 * 16, [&](int f, int ln, int j) {
-                const int ks = f & 15, w = (f >> 4) & 3, ch = f >> 6;
-                return w1[(size_t)(ch * 128 + 32 * w + (ln & 31)) * H + 32 * (ks >> 1) + 16 * (ln >> 5) + 8 * (ks & 1) + j];
+            rc = image(F / 128 * 4 * KS, [&](int f, int ln, int j) {     // [chunk][w][ks]
+                const int ks = f % KS, w = (f / KS) & 3, ch = f / (KS * 4);
+                return w1[(size_t)(ch * 128 + 32 * w + (ln & 31)) * H + panel_k(ks, ln, j)];
             }, &d.w1_img);
             if (rc) return rc;
             const float* w2 = wts->linear2_weight[l];
-            rc = image(F / 128 * 4 * 2 * 8, [&](int f, int ln, int j) {
-                const int ks = f & 7, rb = (f >> 3) & 1, w = (f >> 4) & 3, ch = f >> 6;
-                return w2[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * F + ch * 128 + 32 * (ks >> 1) + 16 * (ks & 1) +
+            rc = image(F / 128 * 4 * RB * 8, [&](int f, int ln, int j) { // [chunk][w][rb][ks8], K = the chunk's h in accumulator order
+                const int ks = f & 7, rb = (f >> 3) % RB, w = (f / (8 * RB)) & 3, ch = f / (8 * RB * 4);
+                return w2[(size_t)(32 * RB * w + 32 * rb + phi(ln & 31)) * F + ch * 128 + 32 * (ks >> 1) + 16 * (ks & 1) +
                           8 * (j >> 2) + 4 * (ln >> 5) + (j & 3)];
             }, &d.w2_img);
             if (rc) return rc;
-            // W_qkv of THIS layer (the previous layer's kernel runs it as its tail): per wave 6 steps of
-            // 32 rows: Q rows 64w + 32 rb + phi, K likewise, V rows in attn_kernel's tile order
+            // W_qkv of THIS layer (the previous layer's kernel runs it as its tail): per wave 3 RB steps of
+            // 32 rows: Q rows 32 RB w + 32 rb + phi, K likewise, V rows in attn_kernel's tile order
             // (V^T row r = natural feature pair_row(r)); K order = the x2 panel's (as W1)
             const float* wq = wts->in_proj_weight[l];
-            rc = image(4 * 6 * 16, [&](int f, int ln, int j) {
-                const int ks = f & 15, st = (f >> 4) % 6, w = f / 96;
-                const int rb = st & 1, kind = st >> 1;
-                const int row = kind < 2 ? kind * H + 64 * w + 32 * rb + phi(ln & 31)
-                                         : 2 * H + pair_row(64 * w + 32 * rb + (ln & 31));
-                return wq[(size_t)row * H + 32 * (ks >> 1) + 16 * (ln >> 5) + 8 * (ks & 1) + j];
+            rc = image(4 * 3 * RB * KS, [&](int f, int ln, int j) {      // [w][step][ks]
+                const int ks = f % KS, st = (f / KS) % (3 * RB), w = f / (KS * 3 * RB);
+                const int rb = st % RB, kind = st / RB;
+                const int row = kind < 2 ? kind * H + 32 * RB * w + 32 * rb + phi(ln & 31)
+                                         : 2 * H + pair_row(32 * RB * w + 32 * rb + (ln & 31));
+                return wq[(size_t)row * H + panel_k(ks, ln, j)];
             }, &d.wq_img);
             if (rc) return rc;
         }
@@ -1062,7 +1066,6 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
             a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32; a.heads = c.heads;
-            if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) if (atoi(v) & 8) a.ao_tiled = 0;
             a.dbg = l == 0 ? e->attn_dbg : nullptr;
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
@@ -1071,9 +1074,10 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             Layer32Args a{};
             a.ao = ao; a.wo_img = d.wo_img; a.w1_img = d.w1_img; a.w2_img = d.w2_img;
             a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2;
-            a.X = X; a.Xb = Xb; a.M = M; a.F = F; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
+            a.X = X; a.Xb = Xb; a.M = M; a.F = F; a.H = H; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
             if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) a.debug_mode = atoi(v);
             qkv_done = e->qkv_fused && l + 1 < c.num_layers;
+            a.write_x = l + 1 < c.num_layers;
             if (qkv_done) {
                 const DevLayer& nx = e->layers[l + 1];
                 a.wq_img = nx.wq_img; a.bq = nx.bqkv; a.qk_out = qk; a.vt_out = vt; a.vt_ld = ws.vt_ld;

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 y.w = live[t] ? pv.w + (valid[t] ? acc[nb][t][3] + bv.w : 0.f) : 0.f;
                 if (inside[t]) {
                     const int m = tok0 + 16 * t + idx;
-                    *reinterpret_cast<float4*>(a.X + (a.x_tiled ? x32_index(m, n) : (size_t)m * a.H + n)) = y;
+                    *reinterpret_cast<float4*>(a.X + (a.x_tiled ? x32_index(m, n, a.H) : (size_t)m * a.H + n)) = y;
                     if constexpr (P::kIsBF16) pair[t].put(a.Xb + ((size_t)m * a.H + (n & ~7)) * 2, nb & 1, y.x, y.y, y.z, y.w);
                 }
             }
@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const int n = head * DH + pair_feature(db, g);
-            pair.put(a.ao + ((a.ao_tiled && P::kIsBF16) ? ao32_byte(m, n & ~7) : ((size_t)m * a.H + (n & ~7)) * P::kBytes), db & 1,
+            pair.put(a.ao + ((a.ao_tiled && P::kIsBF16) ? ao32_byte(m, n & ~7, a.H) : ((size_t)m * a.H + (n & ~7)) * P::kBytes), db & 1,
                      oacc[db][t][0] * inv, oacc[db][t][1] * inv,
                      oacc[db][t][2] * inv, oacc[db][t][3] * inv);
         }

@@ -1,7 +1,8 @@
 // The feature-split layer kernel for gfx950: everything between two attention
 // kernels of one encoder layer (reference: torch TransformerEncoderLayer._sa_block's
 // out_proj, norm1, _ff_block, norm2 -- SURVEY.md 2.3 rows M5/M6 -- and the next
-// layer's in_proj) for a 160-token workgroup, on v_mfma_f32_32x32x16.
+// layer's in_proj) for a 160-token workgroup (hidden 256; 96 tokens at hidden 512),
+// on v_mfma_f32_32x32x16.
 //
 // Why this shape (measured, tools/dma_probe.hip + tools/ffn32_probe.hip):
 //  * one wave issues v_mfma_f32_16x16x32_bf16 every ~21.6 cycles but
@@ -36,18 +37,28 @@
 namespace {
 
 constexpr float kLnEps32 = 1e-5f;
-constexpr int TB = 5;                 // token blocks of 32 per workgroup
-constexpr int HID = 256;              // hidden width (4 waves x 2 row blocks x 32)
 constexpr int HC = 128;               // hidden rows of the FFN per chunk (4 waves x 32)
 
-// LDS map (bytes)
-constexpr int L_ACT = 0;              // token panel: fragments [tb][16 k-steps] of 1 KiB
-constexpr int L_H = 81920;            // h of one chunk: fragments [tb][8 k-steps]
-constexpr int L_LNP1 = 122880;        // [bo | gamma1 | beta1]
-constexpr int L_LNP2 = 125952;        // [b2 | gamma2 | beta2]
-constexpr int L_BQ = 129024;          // next layer's in_proj bias (3 x 256)
-constexpr int L_STATS = 132096;       // LayerNorm partial sums: [2 rounds][4 waves][160]
-constexpr int L_B1 = 137216;          // b1, F floats
+// Geometry of a hidden width: wave w owns features 32 RB w .. + 32 RB - 1 (RB 32-row blocks)
+// of every HIDT-wide result; the workgroup's TBN token blocks of 32 keep the accumulators
+// (RB * TBN + TBN blocks of 16 registers) inside the 256 AGPRs.
+template <int HIDT>
+struct Geo {
+    static_assert(HIDT == 256 || HIDT == 512, "hidden width");
+    static constexpr int RB = HIDT / 128;
+    static constexpr int KS = HIDT / 16;            // 16-wide K-steps of a token-panel row
+    static constexpr int KH = KS / 16;              // halves of 16 K-steps (one register set of fragments each)
+    static constexpr int TBN = HIDT == 256 ? 5 : 3;
+    static constexpr int TOKS = 32 * TBN;
+    // LDS map (bytes)
+    static constexpr int L_ACT = 0;                             // token panel: fragments [tb][KS] of 1 KiB
+    static constexpr int L_H = TBN * KS * 1024;                 // h of one chunk: fragments [tb][8]
+    static constexpr int L_LNP1 = L_H + TBN * 8 * 1024;         // [bo | gamma1 | beta1]
+    static constexpr int L_LNP2 = L_LNP1 + 3 * HIDT * 4;        // [b2 | gamma2 | beta2]
+    static constexpr int L_BQ = L_LNP2 + 3 * HIDT * 4;          // next layer's in_proj bias
+    static constexpr int L_STATS = L_BQ + 3 * HIDT * 4;         // LayerNorm partial sums [2][4 waves][TOKS]
+    static constexpr int L_B1 = L_STATS + 2 * 4 * TOKS * 4;     // b1, F floats
+};
 
 __device__ __forceinline__ uint32_t lds_addr32(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
@@ -116,34 +127,37 @@ __device__ __forceinline__ void stream(uint32_t b0, uint32_t b1, USE use) {
     stream_prime<OFFS, 0, N, D>(ring, b0, b1);
     stream_step<OFFS, 0, N, D>(ring, b0, b1, use);
 }
-// step i = ks * 5 + tb: panel fragment tb * 16 + ks (16 K-steps) / h fragment tb * 8 + ks (8 K-steps)
-struct OffPanel { static constexpr int at(int i) { return ((i % TB) * 16 + i / TB) * 1024; } };
-struct OffH { static constexpr int at(int i) { return ((i % TB) * 8 + i / TB) * 1024; } };
-// FFN phase A in two groups: token blocks 0..2 (step i = ks * 3 + tb), then 3..4 (step i = ks * 2 + tb - 3)
-struct OffPanelA { static constexpr int at(int i) { return ((i % 3) * 16 + i / 3) * 1024; } };
-struct OffPanelB { static constexpr int at(int i) { return ((3 + i % 2) * 16 + i / 2) * 1024; } };
+// Panel stream: step i = (K0 + i / NTB, TB0 + i % NTB) reads panel fragment tb * KS + ks
+template <int KS, int K0, int TB0, int NTB>
+struct OffPanel { static constexpr int at(int i) { return ((TB0 + i % NTB) * KS + K0 + i / NTB) * 1024; } };
+// h stream: step i = (ks = i / TBN, tb = i % TBN) reads h fragment tb * 8 + ks
+template <int TBN>
+struct OffH { static constexpr int at(int i) { return ((i % TBN) * 8 + i / TBN) * 1024; } };
 
 __device__ __forceinline__ float pair_sum(float v) {          // lanes l and l + 32
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <class P, bool QKV>
+template <class P, int HIDT, bool QKV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void layer32_kernel(Layer32Args a) {
+    using G = Geo<HIDT>;
+    constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * (TB * 32);
+    const int m0 = blockIdx.x * TOKS;
     const int NCH = a.F / HC;
     const uint32_t lds0 = lds_addr32(smem);
     const uint32_t voff = lane * 16;
-    const uint32_t pb0 = lds0 + L_ACT + lane * 16, pb1 = pb0 + 65536;   // panel fragments
-    const uint32_t hb0 = lds0 + L_H + lane * 16;                         // h fragments
-    float* lnp1 = reinterpret_cast<float*>(smem + L_LNP1);
-    float* lnp2 = reinterpret_cast<float*>(smem + L_LNP2);
-    float* stats = reinterpret_cast<float*>(smem + L_STATS);
+    const uint32_t pb0 = lds0 + G::L_ACT + lane * 16, pb1 = pb0 + 65536;   // panel fragments
+    const uint32_t hb0 = lds0 + G::L_H + lane * 16;                         // h fragments
+    float* lnp1 = reinterpret_cast<float*>(smem + G::L_LNP1);
+    float* lnp2 = reinterpret_cast<float*>(smem + G::L_LNP2);
+    float* stats = reinterpret_cast<float*>(smem + G::L_STATS);
+    const int fbase = 32 * RB * wave;               // first feature of this wave
 
 #ifdef PPG_FFN_TIMING
     auto pstamp = [&](int k) {
@@ -155,115 +169,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(0);
 
     u32x4 w1f[16], w2f[16];
-    // ---- attention output (AO32 order: this tile's 80 fragments are one contiguous 80 KiB) -> LDS panel
-    if (a.debug_mode & 8) {          // bisecting: row-major attention output
-        uint32_t rowoff[TB];
+    // 16 fragments (1 KiB each, consecutive) -> one register set
+    auto load16 = [&](u32x4 (&wf)[16], const char* base) {
+        [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
+    };
+    // ---- attention output (AO32 order: this tile's fragments are one contiguous block) -> LDS panel
+    {
+        const char* tile = a.ao + (size_t)blockIdx.x * (TB * KS * 1024);
 #pragma unroll
-        for (int t = 0; t < TB; ++t) rowoff[t] = (uint32_t)min(m0 + 32 * t + tok, a.M - 1) * (HID * 2) + hh * 16;
-#pragma unroll
-        for (int i = 0; i < TB * 16 / 4; ++i) {
+        for (int i = 0; i < TB * KS / 4; ++i) {
             const int p = 4 * i + wave;
-            const int t = p >> 4, ks = p & 15;
-            uint32_t ro = rowoff[0];
-#pragma unroll
-            for (int u = 1; u < TB; ++u) ro = (t == u) ? rowoff[u] : ro;
-            glds16(a.ao, ro + ks * 32, lds0 + L_ACT + p * 1024);
-        }
-    } else {
-        const char* tile = a.ao + (size_t)blockIdx.x * (TB * 16 * 1024);
-#pragma unroll
-        for (int i = 0; i < TB * 16 / 4; ++i) {
-            const int p = 4 * i + wave;
-            glds16(tile + (size_t)p * 1024, voff, lds0 + L_ACT + p * 1024);
+            glds16(tile + (size_t)p * 1024, voff, lds0 + G::L_ACT + p * 1024);
         }
     }
-    f32x16 yacc[2][TB];
+    f32x16 yacc[RB][TB];
     // parameters: every global load first, the LDS stores afterwards (one memory round trip, not three)
     {
-        const int i = tid;                       // 192 float4 per parameter triple
-        const int v = i / (HID / 4), j = i - v * (HID / 4);
-        float4 p1 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p1, pq = p1;
-        if (i < 3 * HID / 4) {
-            p1 = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
-            p2 = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
-            if constexpr (QKV) pq = reinterpret_cast<const float4*>(a.bq)[i];
+        constexpr int NP = (3 * HIDT / 4 + 255) / 256;
+        float4 p1[NP], p2[NP], pq[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + 256 * u;
+            const int v = i / (HIDT / 4), j = i - v * (HIDT / 4);
+            if (i < 3 * HIDT / 4) {
+                p1[u] = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
+                p2[u] = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
+                if constexpr (QKV) pq[u] = reinterpret_cast<const float4*>(a.bq)[i];
+            }
         }
         constexpr int B1MAX = 8;                 // F <= 8192
         float4 pb[B1MAX];
 #pragma unroll
         for (int u = 0; u < B1MAX; ++u)
             if (tid + 256 * u < a.F / 4) pb[u] = reinterpret_cast<const float4*>(a.b1)[tid + 256 * u];
-        if (i < 3 * HID / 4) {
-            reinterpret_cast<float4*>(lnp1)[i] = p1;
-            reinterpret_cast<float4*>(lnp2)[i] = p2;
-            if constexpr (QKV) reinterpret_cast<float4*>(smem + L_BQ)[i] = pq;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + 256 * u;
+            if (i < 3 * HIDT / 4) {
+                reinterpret_cast<float4*>(lnp1)[i] = p1[u];
+                reinterpret_cast<float4*>(lnp2)[i] = p2[u];
+                if constexpr (QKV) reinterpret_cast<float4*>(smem + G::L_BQ)[i] = pq[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < B1MAX; ++u)
-            if (tid + 256 * u < a.F / 4) reinterpret_cast<float4*>(smem + L_B1)[tid + 256 * u] = pb[u];
+            if (tid + 256 * u < a.F / 4) reinterpret_cast<float4*>(smem + G::L_B1)[tid + 256 * u] = pb[u];
     }
-    // ---- W_o fragments of this wave (2 row blocks x 16 K-steps) straight to registers.  Issued
-    // only now: registers written by an asm load must not be spilled before the data is in, and
-    // the compiler does not know they are in flight -- nothing register-hungry may sit between
+    // ---- out-projection: y[rb][tb] = W_o[rows of this wave] ao.  W_o fragments go straight to
+    // registers, two row blocks x 16 K-steps at a time (image order [wave][rb][ks]).  They are issued
+    // only here: registers written by an asm load must not be moved or spilled before the data is in,
+    // and the compiler does not know they are in flight -- nothing register-hungry may sit between
     // such a load and its wait.
-    {
-        const char* base = a.wo_img + (size_t)wave * 32768;
-        [&]<int... K>(std::integer_sequence<int, K...>) {
-            (gload_frag<K>(w1f[K], voff, base), ...);
-            (gload_frag<K>(w2f[K], voff, base + 16384), ...);
-        }(std::make_integer_sequence<int, 16>{});
-    }
-    vm_wait_all(w1f);
-    vm_wait_all(w2f);
-    __syncthreads();
-    pstamp(1);
-
-    // ---- out-projection: y[rb][tb] = W_o[rows of this wave] ao --------------------------------
-    if (!(a.debug_mode & 1)) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        stream<OffPanel, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int ks = i / TB, tb = i % TB;
-            if constexpr (ks == 0) {
-                yacc[0][tb] = P::mma32(w1f[0], bf, zero);
-                yacc[1][tb] = P::mma32(w2f[0], bf, zero);
-            } else {
-                yacc[0][tb] = P::mma32(w1f[ks], bf, yacc[0][tb]);
-                yacc[1][tb] = P::mma32(w2f[ks], bf, yacc[1][tb]);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    [&]<int... R>(std::integer_sequence<int, R...>) {
+        ([&] {
+            constexpr int rbp = R / KH, kh = R % KH;             // row-block pair, K half
+            const char* base = a.wo_img + ((size_t)wave * RB * KS) * 1024;
+            load16(w1f, base + ((size_t)(2 * rbp) * KS + 16 * kh) * 1024);
+            load16(w2f, base + ((size_t)(2 * rbp + 1) * KS + 16 * kh) * 1024);
+            vm_wait_all(w1f);
+            vm_wait_all(w2f);
+            if constexpr (R == 0) {
+                __syncthreads();                             // panel and parameters are in LDS
+                pstamp(1);
             }
-        });
-    }
+            if (!(a.debug_mode & 1)) {
+                stream<OffPanel<KS, 16 * kh, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / TB, tb = i % TB;
+                    if constexpr (ks == 0 && kh == 0) {
+                        yacc[2 * rbp][tb] = P::mma32(w1f[0], bf, zero);
+                        yacc[2 * rbp + 1][tb] = P::mma32(w2f[0], bf, zero);
+                    } else {
+                        yacc[2 * rbp][tb] = P::mma32(w1f[ks], bf, yacc[2 * rbp][tb]);
+                        yacc[2 * rbp + 1][tb] = P::mma32(w2f[ks], bf, yacc[2 * rbp + 1][tb]);
+                    }
+                });
+            }
+        }(), ...);
+    }(std::make_integer_sequence<int, (RB / 2) * KH>{});
     pstamp(2);
-    // W1 fragments of chunk 0 travel while LayerNorm-1 runs
-    auto load_w1 = [&](int c) {
-        const char* base = a.w1_img + ((size_t)c * 4 + wave) * 16384;
-        [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(w1f[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
-    };
 
-    // ---- LayerNorm over the 256 features of a token, spread over the four waves ---------------
+    // ---- LayerNorm over the HIDT features of a token, spread over the four waves ---------------
     // acc <- LN(acc + bias [+ X]) * gamma + beta; `emit(tb, rb, y)` gets the 16 results of a block.
     // One pass for the statistics (sum and sum of squares in fp32: the inputs are O(1) residual
     // sums, var = E[v^2] - mean^2 loses nothing the 16-bit operands have not lost already), one
-    // exchange through LDS, gamma / beta of the lane's 32 features in registers for all 5 blocks.
-    float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * 2 * 4 * 256) + lane * 4;   // this lane's X32 slots
+    // exchange through LDS.
+    float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 4 * 256) + lane * 4;   // this lane's X32 slots
     auto layer_norm = [&](auto residual_tag, const float* lnp, auto emit) {
         constexpr bool RES = decltype(residual_tag)::value;
         constexpr int STAMP = RES ? 7 : 9;
-        float4 bias4[2][4];
+        // the lane's parameter quads: in registers for all token blocks at hidden 256 (2 x 4 quads),
+        // re-read from LDS per block at hidden 512 (they would take 192 registers)
+        constexpr bool KEEP = RB == 2;
+        float4 bias4[KEEP ? RB : 1][4], gv[KEEP ? RB : 1][4], ev[KEEP ? RB : 1][4];
+        auto quad = [&](int which, int rb, int q) { return *reinterpret_cast<const float4*>(lnp + which * HIDT + fbase + 32 * rb + 16 * hh + 4 * q); };
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bias4[rb][q] = *reinterpret_cast<const float4*>(lnp + 64 * wave + 32 * rb + 16 * hh + 4 * q);
+                for (int q = 0; q < 4; ++q) bias4[rb][q] = quad(0, rb, q);
+        }
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             float sum = 0.f, sq = 0.f;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 bv = bias4[rb][q];
+                    float4 bv;
+                    if constexpr (KEEP) bv = bias4[rb][q]; else bv = quad(0, rb, q);
                     if constexpr (RES) {     // X32 order: one contiguous KiB per load instruction
-                        const float4 rv = *reinterpret_cast<const float4*>(xt + ((t * 2 + rb) * 4 + q) * 256);
+                        const float4 rv = *reinterpret_cast<const float4*>(xt + ((t * RB + rb) * 4 + q) * 256);
                         bv.x += rv.x; bv.y += rv.y; bv.z += rv.z; bv.w += rv.w;
                     }
                     yacc[rb][t][4 * q + 0] += bv.x; yacc[rb][t][4 * q + 1] += bv.y;
@@ -278,56 +295,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             sum = pair_sum(sum);
             sq = pair_sum(sq);
             if (hh == 0) {
-                stats[wave * 160 + 32 * t + tok] = sum;
-                stats[640 + wave * 160 + 32 * t + tok] = sq;
+                stats[wave * TOKS + 32 * t + tok] = sum;
+                stats[4 * TOKS + wave * TOKS + 32 * t + tok] = sq;
             }
         }
-        float4 gv[2][4], ev[2][4];
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = 64 * wave + 32 * rb + 16 * hh + 4 * q;
-                gv[rb][q] = *reinterpret_cast<const float4*>(lnp + HID + n);
-                ev[rb][q] = *reinterpret_cast<const float4*>(lnp + 2 * HID + n);
-            }
+                for (int q = 0; q < 4; ++q) { gv[rb][q] = quad(1, rb, q); ev[rb][q] = quad(2, rb, q); }
+        }
         pstamp(STAMP);
         __syncthreads();
         pstamp(STAMP + 1);
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
             const float* s = stats + 32 * t + tok;
-            const float mean = ((s[0] + s[160]) + (s[320] + s[480])) * (1.0f / HID);
-            const float ex2 = ((s[640] + s[800]) + (s[960] + s[1120])) * (1.0f / HID);
+            const float mean = ((s[0] + s[TOKS]) + (s[2 * TOKS] + s[3 * TOKS])) * (1.0f / HIDT);
+            const float ex2 = ((s[4 * TOKS] + s[5 * TOKS]) + (s[6 * TOKS] + s[7 * TOKS])) * (1.0f / HIDT);
             const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + kLnEps32);
             const float shift = -mean * rstd;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    yacc[rb][t][4 * q + 0] = fmaf(fmaf(yacc[rb][t][4 * q + 0], rstd, shift), gv[rb][q].x, ev[rb][q].x);
-                    yacc[rb][t][4 * q + 1] = fmaf(fmaf(yacc[rb][t][4 * q + 1], rstd, shift), gv[rb][q].y, ev[rb][q].y);
-                    yacc[rb][t][4 * q + 2] = fmaf(fmaf(yacc[rb][t][4 * q + 2], rstd, shift), gv[rb][q].z, ev[rb][q].z);
-                    yacc[rb][t][4 * q + 3] = fmaf(fmaf(yacc[rb][t][4 * q + 3], rstd, shift), gv[rb][q].w, ev[rb][q].w);
+                    float4 g4, e4;
+                    if constexpr (KEEP) { g4 = gv[rb][q]; e4 = ev[rb][q]; } else { g4 = quad(1, rb, q); e4 = quad(2, rb, q); }
+                    yacc[rb][t][4 * q + 0] = fmaf(fmaf(yacc[rb][t][4 * q + 0], rstd, shift), g4.x, e4.x);
+                    yacc[rb][t][4 * q + 1] = fmaf(fmaf(yacc[rb][t][4 * q + 1], rstd, shift), g4.y, e4.y);
+                    yacc[rb][t][4 * q + 2] = fmaf(fmaf(yacc[rb][t][4 * q + 2], rstd, shift), g4.z, e4.z);
+                    yacc[rb][t][4 * q + 3] = fmaf(fmaf(yacc[rb][t][4 * q + 3], rstd, shift), g4.w, e4.w);
                 }
                 emit(t, rb, yacc[rb][t]);
             }
         }
     };
-    // the 16 results of block (tb, rb), packed: K-steps 4w + 2rb, 4w + 2rb + 1 of the token panel
+    // the 16 results of block (tb, rb), packed: K-steps 2 RB w + 2 rb, + 1 of the token panel
     // (slot 4e + r of K-step s' = register 4 (2s' + e) + r = natural feature 32 (ks/2) + 16 hh + 8 (ks%2) + 4e + r)
     auto panel_write = [&](int t, int rb, const f32x16& y) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const u32x4 frag = u32x4{P::pack2(y[8 * s + 0], y[8 * s + 1]), P::pack2(y[8 * s + 2], y[8 * s + 3]),
                                      P::pack2(y[8 * s + 4], y[8 * s + 5]), P::pack2(y[8 * s + 6], y[8 * s + 7])};
-            asm volatile("ds_write_b128 %0, %1" :: "v"(pb0 + (uint32_t)((t * 16 + 4 * wave + 2 * rb + s) * 1024)), "v"(frag) : "memory");
+            const uint32_t addr = pb0 + (uint32_t)((t * KS + 2 * RB * wave + 2 * rb + s) * 1024);
+            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
         }
     };
     // LayerNorm-1: the panel holds x1 afterwards (every wave finished reading the attention
-    // output two barriers ago), the accumulators keep x1 as the FFN's residual
+    // output a barrier ago), the accumulators keep x1 as the FFN's residual
     layer_norm(std::true_type{}, lnp1, panel_write);
-    load_w1(0);
+    // W1 fragments of chunk 0 (image order [chunk][wave][ks]); nothing register-hungry follows before their wait
+    load16(w1f, a.w1_img + ((size_t)wave * KS) * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     pstamp(3);
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             u32x4 braw[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ds_read128<0>(braw[q], lds0 + L_B1 + (uint32_t)((c * HC + 32 * wave + 8 * q + 4 * hh) * 4));
+            for (int q = 0; q < 4; ++q) ds_read128<0>(braw[q], lds0 + G::L_B1 + (uint32_t)((c * HC + 32 * wave + 8 * q + 4 * hh) * 4));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -354,7 +372,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         vm_wait_all(w1f);
-        const char* w2base = a.w2_img + ((size_t)c * 4 + wave) * 16384;
+        const char* w1c = a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024;          // this chunk's W1 fragments [ks]
+        const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;      // this chunk's W2 fragments [rb][ks8]
+        // what goes into the W1 register set after this chunk: the next chunk's first 16 fragments; after the
+        // last chunk the first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
+        const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
+                            : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1c);
         f32x16 hacc[TB];
         // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
         auto h_write = [&](auto t_tag, auto s_tag) {
@@ -364,49 +387,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
             asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
         };
-        // token blocks 0..2 first (48 steps), then 3..4 (32 steps) with the h of the first three packed
-        // and written between their MFMAs: only two blocks' worth of packing is left after the stream
-        stream<OffPanelA, 16 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int ks = i / 3, tb = i % 3;
-            if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-            else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-            // this chunk's W2 fragments
-            if constexpr (i % 5 == 2) gload_frag<i / 5>(w2f[i / 5], voff, w2base);
-        });
-        cstamp(1);
-        stream<OffPanelB, 16 * 2, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int ks = i / 2, tb = 3 + i % 2;
-            // (every wave is long done reading the previous chunk's h: the barrier costs its instruction)
-            if constexpr (i == 0) __builtin_amdgcn_s_barrier();
-            if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-            else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-            if constexpr (i % 5 == 2 && 10 + i / 5 < 16) gload_frag<10 + i / 5>(w2f[10 + i / 5], voff, w2base);
-            if constexpr (i % 5 == 1 && i / 5 < 6) h_write(std::integral_constant<int, (i / 5) / 2>{}, std::integral_constant<int, (i / 5) % 2>{});
-        });
-        cstamp(2);
-        h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-        h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
-        h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
-        h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cstamp(3);
-        __syncthreads();
-        cstamp(4);
-        vm_wait_all(w2f);
-        // next into the W1 registers: the next chunk's fragments; after the last chunk the first
-        // step of the Q/K/V tail (or, without a tail, the chunk's own fragments again: harmless)
-        const char* w1base = c + 1 < NCH ? a.w1_img + ((size_t)(c + 1) * 4 + wave) * 16384
-                             : (QKV ? a.wq_img + (size_t)wave * 6 * 16384 : a.w1_img + ((size_t)c * 4 + wave) * 16384);
-        stream<OffH, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int ks = i / TB, tb = i % TB;
-            yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
-            yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
-            // the next chunk's W1 fragments, two loads per 10 MFMAs
-            if constexpr (tb == 1 || tb == 3) gload_frag<2 * ks + (tb == 3)>(w1f[2 * ks + (tb == 3)], voff, w1base);
-        });
+        if constexpr (HIDT == 256) {
+            // token blocks 0..2 first (48 steps), then 3..4 (32 steps) with the h of the first three packed
+            // and written between their MFMAs: only two blocks' worth of packing is left after the stream
+            stream<OffPanel<KS, 0, 0, 3>, 16 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / 3, tb = i % 3;
+                if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+                else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                // this chunk's W2 fragments
+                if constexpr (i % 5 == 2) gload_frag<i / 5>(w2f[i / 5], voff, w2c);
+            });
+            cstamp(1);
+            stream<OffPanel<KS, 0, 3, 2>, 16 * 2, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / 2, tb = 3 + i % 2;
+                // (every wave is long done reading the previous chunk's h: the barrier costs its instruction)
+                if constexpr (i == 0) __builtin_amdgcn_s_barrier();
+                if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+                else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                if constexpr (i % 5 == 2 && 10 + i / 5 < 16) gload_frag<10 + i / 5>(w2f[10 + i / 5], voff, w2c);
+                if constexpr (i % 5 == 1 && i / 5 < 6) h_write(std::integral_constant<int, (i / 5) / 2>{}, std::integral_constant<int, (i / 5) % 2>{});
+            });
+            cstamp(2);
+            h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+            h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+            h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
+            h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cstamp(3);
+            __syncthreads();
+            cstamp(4);
+            vm_wait_all(w2f);
+            stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
+                yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                // the next chunk's W1 fragments, two loads per 10 MFMAs
+                if constexpr (tb == 1 || tb == 3) gload_frag<2 * ks + (tb == 3)>(w1f[2 * ks + (tb == 3)], voff, next1);
+            });
+        } else {
+            // hidden 512: 32 W1 and 32 W2 fragments per chunk pass through the two register sets in halves:
+            // A1 (W1 ks 0..15 in set 1) | A2 (ks 16..31 in set 2) | B1 (W2 row blocks 0, 1 in set 1) | B2 (2, 3 in set 2),
+            // each half prefetching the other set
+            stream<OffPanel<KS, 0, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+                else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                if constexpr (i % 3 == 1) gload_frag<16 + i / 3>(w2f[i / 3], voff, w1c);
+            });
+            vm_wait_all(w2f);
+            cstamp(1);
+            stream<OffPanel<KS, 16, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                if constexpr (i == 0) __builtin_amdgcn_s_barrier();        // the previous chunk's h is read
+                hacc[tb] = P::mma32(w2f[ks], bf, hacc[tb]);
+                if constexpr (i % 3 == 1) gload_frag<i / 3>(w1f[i / 3], voff, w2c);
+            });
+            cstamp(2);
+            [&]<int... U>(std::integer_sequence<int, U...>) {
+                (h_write(std::integral_constant<int, U / 2>{}, std::integral_constant<int, U % 2>{}), ...);
+            }(std::make_integer_sequence<int, 2 * TB>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cstamp(3);
+            __syncthreads();
+            cstamp(4);
+            vm_wait_all(w1f);
+            stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                yacc[0][tb] = P::mma32(w1f[ks], bf, yacc[0][tb]);
+                yacc[1][tb] = P::mma32(w1f[8 + ks], bf, yacc[1][tb]);
+                if constexpr (i < 16) gload_frag<16 + i>(w2f[i], voff, w2c);
+            });
+            vm_wait_all(w2f);
+            stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                yacc[2][tb] = P::mma32(w2f[ks], bf, yacc[2][tb]);
+                yacc[3][tb] = P::mma32(w2f[8 + ks], bf, yacc[3][tb]);
+                if constexpr (i < 16) gload_frag<i>(w1f[i], voff, next1);
+            });
+        }
         cstamp(5);
     }
     vm_wait_all(w1f);
@@ -414,13 +479,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- LayerNorm-2 -> X (fp32 residual stream, X32 order: one KiB per store) and its row-major 16-bit copy
     layer_norm(std::false_type{}, lnp2, [&](int t, int rb, const f32x16& y) {
+        if (a.write_x) {                                    // (the last layer's residual stream has no reader)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(xt + ((t * 2 + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(xt + ((t * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        }
         if constexpr (QKV) panel_write(t, rb, y);          // x2: the B operand of the Q/K/V tail
         const int m = m0 + 32 * t + tok;
         if (a.Xb && m < a.M) {
-            char* brow = a.Xb + ((size_t)m * HID + 64 * wave + 32 * rb + 16 * hh) * 2;
+            char* brow = a.Xb + ((size_t)m * HIDT + fbase + 32 * rb + 16 * hh) * 2;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 *reinterpret_cast<u32x4*>(brow + 16 * s) = u32x4{P::pack2(y[8 * s + 0], y[8 * s + 1]), P::pack2(y[8 * s + 2], y[8 * s + 3]),
@@ -431,14 +498,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     if constexpr (QKV) {
         // ---- the next layer's Q/K/V projection on x2 ------------------------------------------
-        // Six steps of one 32-row block each: Q and K features 64w..64w+63 (row-major stores,
-        // a lane owns 16 consecutive features of its token) and V features 64w..64w+63 with the
-        // MFMA operands swapped, so that the accumulator comes out transposed for V^T (a lane owns
-        // one V^T row and 16 tokens).  W fragments alternate between the two 16-fragment register
-        // sets: the next step's travel under this step's MFMAs.
+        // 3 RB steps of one 32-row block each: Q and K features of this wave (row-major stores, a lane
+        // owns 16 consecutive features of its token) and its V features with the MFMA operands swapped,
+        // so that the accumulator comes out transposed for V^T (a lane owns one V^T row and 16 tokens).
+        // Every step takes KH half-steps of 16 W fragments (image order [wave][step][ks]); the two register
+        // sets alternate: the next half-step's fragments travel under this one's MFMAs.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                       // x2 panel complete
-        const float* bq = reinterpret_cast<const float*>(smem + L_BQ);
+        const float* bq = reinterpret_cast<const float*>(smem + G::L_BQ);
         // transposed-V columns of the wave-uniform 16-token halves of every token block
         int vcol[TB][2];
         bool valigned[TB];
@@ -458,35 +525,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             valigned[t] = vcol[t][0] >= 0 && vcol[t][1] == vcol[t][0] + 4 && (vcol[t][0] & 31) == 0;
         }
-        // (step 0's fragments arrived with the last FFN chunk)
-        auto step = [&](auto step_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
-            constexpr int STEP = decltype(step_tag)::value;
-            constexpr bool SWAP = STEP >= 4;
-            const char* nbase = a.wq_img + (((size_t)wave * 6 + (STEP + 1 < 6 ? STEP + 1 : STEP)) * 16) * 1024;
-            f32x16 acc[TB];
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            stream<OffPanel, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+        const char* wq = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
+        f32x16 acc[TB];
+        auto half_step = [&](auto hs_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
+            constexpr int HS = decltype(hs_tag)::value;
+            constexpr int STEP = HS / KH, kh = HS % KH;
+            constexpr int KIND = STEP / RB, RBI = STEP % RB;        // 0 Q, 1 K, 2 V; row block inside the wave's features
+            constexpr bool SWAP = KIND == 2;
+            constexpr bool LAST = HS + 1 == 3 * RB * KH;
+            const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
+            stream<OffPanel<KS, 16 * kh, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ks = i / TB, tb = i % TB;
-                if constexpr (ks == 0) acc[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
+                if constexpr (ks == 0 && kh == 0) acc[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
                 else acc[tb] = SWAP ? P::mma32(bf, cur[ks], acc[tb]) : P::mma32(cur[ks], bf, acc[tb]);
-                // the next step's fragments: issued in the first 48 of the 80 stream steps so that ...
-                if constexpr (STEP + 1 < 6 && i % 3 == 0 && i < 48) gload_frag<i / 3>(nxt[i / 3], voff, nbase);
+                // the next half-step's fragments: issued in the first three fifths of the stream so that ...
+                if constexpr (!LAST && i % 3 == 0 && i / 3 < 16) gload_frag<i / 3>(nxt[i / 3], voff, nbase);
             });
             // ... they have landed here: the epilogue below is ordinary compiler code, which may move or
             // spill registers it believes ready (an asm load's destination must be waited for before that)
-            if constexpr (STEP + 1 < 6) vm_wait_all(nxt);
+            if constexpr (!LAST) vm_wait_all(nxt);
+            if constexpr (kh + 1 < KH) return;
             if constexpr (!SWAP) {
-                // Q (steps 0, 1) / K (steps 2, 3): row m, features 256 (STEP / 2) + 64 w + 32 (STEP % 2) + 16 hh .. + 15
-                constexpr int n0 = 256 * (STEP / 2) + 32 * (STEP % 2);
+                // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh .. + 15
+                constexpr int n0 = HIDT * KIND + 32 * RBI;
                 float4 b4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bq + n0 + 64 * wave + 16 * hh + 4 * q);
+                for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bq + n0 + fbase + 16 * hh + 4 * q);
 #pragma unroll
                 for (int t = 0; t < TB; ++t) {
                     const int m = m0 + 32 * t + tok;
                     if (m >= a.M) continue;
-                    char* dst = a.qk_out + ((size_t)m * 2 * HID + n0 + 64 * wave + 16 * hh) * 2;
+                    char* dst = a.qk_out + ((size_t)m * 2 * HIDT + n0 + fbase + 16 * hh) * 2;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
@@ -496,11 +566,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
             } else {
-                // V: lane = V^T row 64 w + 32 (STEP - 4) + (l & 31) (natural feature pair_row(row): attn_kernel's
+                // V: lane = V^T row fbase + 32 RBI + (l & 31) (natural feature pair_row(row): attn_kernel's
                 // tile order), registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of
                 // every 32-token group of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
-                const int vrow = 64 * wave + 32 * (STEP - 4) + tok;
-                const float bv = bq[2 * HID + pair_row(vrow)];
+                const int vrow = fbase + 32 * RBI + tok;
+                const float bv = bq[2 * HIDT + pair_row(vrow)];
                 char* rowp = a.vt_out + (size_t)vrow * a.vt_ld * 2;
 #pragma unroll
                 for (int t = 0; t < TB; ++t) {
@@ -525,22 +595,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         };
-        step(std::integral_constant<int, 0>{}, w1f, w2f);
-        step(std::integral_constant<int, 1>{}, w2f, w1f);
-        step(std::integral_constant<int, 2>{}, w1f, w2f);
-        step(std::integral_constant<int, 3>{}, w2f, w1f);
-        step(std::integral_constant<int, 4>{}, w1f, w2f);
-        step(std::integral_constant<int, 5>{}, w2f, w1f);
+        // (half-step 0's fragments arrived in set 1 with the last FFN chunk)
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            ((S % 2 == 0 ? half_step(std::integral_constant<int, S>{}, w1f, w2f)
+                         : half_step(std::integral_constant<int, S>{}, w2f, w1f)), ...);
+        }(std::make_integer_sequence<int, 3 * RB * KH>{});
         pstamp(6);
     }
 }
 
-template <class P>
-hipError_t launch_layer32_p(const Layer32Args& a, hipStream_t s) {
+template <class P, int HIDT>
+hipError_t launch_layer32_h(const Layer32Args& a, hipStream_t s) {
+    using G = Geo<HIDT>;
     if (a.F % HC || a.F < HC || a.M <= 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)L_B1 + (size_t)a.F * 4;
-    if (lds > 163840) return hipErrorInvalidValue;
-    const dim3 grid((a.M + TB * 32 - 1) / (TB * 32));
+    const size_t lds = (size_t)G::L_B1 + (size_t)a.F * 4;
+    if (lds > 163840 || a.F > 8192) return hipErrorInvalidValue;
+    const dim3 grid((a.M + G::TOKS - 1) / G::TOKS);
     auto launch = [&](auto kern) {
         static ppg::LdsLimit limit;
         const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
@@ -548,13 +618,22 @@ hipError_t launch_layer32_p(const Layer32Args& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
         return hipGetLastError();
     };
-    if (a.wq_img != nullptr) return launch(layer32_kernel<P, true>);
-    return launch(layer32_kernel<P, false>);
+    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true>);
+    return launch(layer32_kernel<P, HIDT, false>);
+}
+
+template <class P>
+hipError_t launch_layer32_p(const Layer32Args& a, hipStream_t s) {
+    if (a.H == 256) return launch_layer32_h<P, 256>(a, s);
+    if (a.H == 512) return launch_layer32_h<P, 512>(a, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
 namespace ppg {
+
+int layer32_tokens(int hidden) { return hidden == 512 ? Geo<512>::TOKS : Geo<256>::TOKS; }
 
 hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s) {
     if (precision == PPG_PRECISION_BF16) return launch_layer32_p<PrecBF16>(a, s);

@@ -65,11 +65,17 @@ def last_hidden_state(model, padded, mask):
     attention mask -> feature_projection -> encoder."""
     if os.environ.get('PPGS_AMD_W2V2_NATIVE', '1') == '0':
         return model(padded, mask).last_hidden_state
+    from .. import core
     extract = feature_encoder_for(padded.device, model)(padded)
     attention_mask = model._get_feature_vector_attention_mask(
         extract.shape[1], mask, add_adapter=False)
-    hidden, _ = model.feature_projection(extract)
-    return model.encoder(hidden, attention_mask=attention_mask).last_hidden_state
+    # the projection and the transformer are still the HF modules: in the 16-bit engine modes they
+    # run under fp16 autocast, which is how the reference itself runs the whole model on a GPU
+    # (ppgs/preprocess/core.py:207: torch.autocast('cuda')); fp32 engine mode: fp32 throughout
+    with torch.autocast('cuda', dtype=torch.float16, enabled=core.PRECISION != 'fp32'):
+        hidden, _ = model.feature_projection(extract)
+        out = model.encoder(hidden, attention_mask=attention_mask).last_hidden_state
+    return out.float()
 
 
 def from_audios(audio, lengths, sample_rate=None, gpu=None):

@@ -57,7 +57,7 @@ def main():
         'ppg_network': {
             'ms_per_step': ms, 'frames_per_s': 16000 / ms * 1e3, 'end_to_end_tflops': flops / ms / 1e9,
             'kernel_ms_per_step': kernels,
-            'roofline': {'kernel': 'layer kernel at hidden 512 (token-split ffn_kernel<NT=1, 32 blocks>)', 'bound': 'mfma',
+            'roofline': {'kernel': 'layer32_kernel<hidden 512> (feature-split, 96-token workgroups; token-split ffn_kernel in fp32 mode)', 'bound': 'mfma',
                          'achieved': layer_flops / layer_ms / 1e9, 'peak': PEAK[precision], 'unit': 'TFLOP/s',
                          'frac': layer_flops / layer_ms / 1e9 / PEAK[precision], 'mean_launch_ms': layer_ms}},
     }
@@ -78,10 +78,14 @@ def main():
             torch_ms = timed(lambda: hf.feature_extractor(audio), steps=5, warmup=2)
             extract = hf.feature_extractor(audio).transpose(1, 2)
             body_ms = timed(lambda: hf.encoder(hf.feature_projection(extract)[0]), steps=5, warmup=2)
+            with torch.autocast('cuda', dtype=torch.float16):
+                body16_ms = timed(lambda: hf.encoder(hf.feature_projection(extract)[0]), steps=5, warmup=2)
         record['feature_encoder_hip'] = {'ms': hip_ms, 'tflops': conv_flops / hip_ms / 1e9, 'flops': conv_flops}
         record['feature_encoder_pytorch_fp32'] = {'ms': torch_ms, 'tflops': conv_flops / torch_ms / 1e9}
         record['w2v2_transformer_pytorch_fp32'] = {'ms': body_ms}
-        record['end_to_end_ms'] = {'native_encoder': hip_ms + body_ms + ms, 'all_pytorch_w2v2': torch_ms + body_ms + ms}
+        record['w2v2_transformer_pytorch_fp16_autocast'] = {'ms': body16_ms}
+        record['end_to_end_ms'] = {'native_encoder_fp16_body': hip_ms + body16_ms + ms, 'native_encoder_fp32_body': hip_ms + body_ms + ms,
+                                   'all_pytorch_fp32_w2v2': torch_ms + body_ms + ms}
     except Exception as error:                                    # transformers missing: kernel path only
         record['feature_encoder'] = f'skipped: {error}'
     print(json.dumps(record))
