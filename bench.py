@@ -465,15 +465,19 @@ def rank_main(args):
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
+    line = None
     try:
         line = (run_c2 if args.workload == 'c2' else run_c4)(args, rank, world, local_rank, use_dist)
-        if rank == 0:
-            if use_dist:
-                line['rccl_world_size'] = dist.get_world_size()
-            print(json.dumps(line), flush=True)
+        if rank == 0 and use_dist:
+            line['rccl_world_size'] = dist.get_world_size()
     finally:
         if use_dist:
             dist.destroy_process_group()
+    # (after the process group is gone: RCCL prints its version banner on stdout when it shuts down,
+    # and the JSON record has to be the LAST line)
+    if rank == 0 and line is not None:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 def _spawned(local_rank, args, port):
