@@ -75,7 +75,7 @@ struct Plan {
     PpgPlanInfo info{};
 };
 
-void split_groups(Plan* plan, int ngroups, int qtile) {
+void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads) {
     plan->groups.clear();
     const int total = plan->info.tokens;
     size_t w = 0;
@@ -105,6 +105,27 @@ void split_groups(Plan* plan, int ngroups, int qtile) {
         std::stable_sort(grp.items.begin(), grp.items.end(), [&](const AttnItem& x, const AttnItem& y) {
             return grp.windows[x.window].valid > grp.windows[y.window].valid;
         });
+        // XCD affinity: workgroup b of the 1-D attention grid runs (item b / heads, head b % heads) and goes to
+        // XCD b % 8, each XCD with its own L2.  Deal the windows (in sorted order) into S = 8 / gcd(8, heads)
+        // lanes and interleave the lanes, so that all query tiles of one (window, head) -- which stream the same
+        // K and V^T rows -- sit S items apart and land on one XCD instead of four.
+        if (xcd_heads > 0) {
+            int g = xcd_heads; for (int b = 8; b; ) { const int t = g % b; g = b; b = t; }   // gcd(heads, 8)
+            const int S = 8 / g;
+            if (S > 1) {
+                std::vector<std::vector<AttnItem>> lane(S);
+                int rank = -1, last = -1;
+                for (const AttnItem& it : grp.items) {
+                    if (it.window != last) { ++rank; last = it.window; }
+                    lane[rank % S].push_back(it);
+                }
+                std::vector<size_t> at(S, 0);
+                size_t out = 0;
+                while (out < grp.items.size())
+                    for (int j = 0; j < S; ++j)
+                        if (at[j] < lane[j].size()) grp.items[out++] = lane[j][at[j]++];
+            }
+        }
         plan->groups.push_back(std::move(grp));
     }
 }
@@ -234,6 +255,7 @@ struct PpgEngine {
     int ffn_split_max = 0;   // PPGS_AMD_FFN_SPLIT_MAX: cap on the hidden splits (0: half the chunks)
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
+    bool attn_xcd = true;    // attention items interleaved so that the query tiles of one (window, head) share an XCD's L2 (PPGS_AMD_ATTN_XCD=0: plain longest-first order)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
@@ -456,7 +478,7 @@ int group_count(const PpgEngine* e, int tokens) {
 }
 
 size_t finish_plan(const PpgEngine* e, Plan* p) {
-    split_groups(p, group_count(e, p->info.tokens), ppg::attn_query_tile(e->head_dim));
+    split_groups(p, group_count(e, p->info.tokens), ppg::attn_query_tile(e->head_dim), e->attn_xcd ? e->cfg.heads : 0);
     size_t off = 0;
     for (PlanGroup& grp : p->groups) {
         grp.ws_offset = off;
@@ -789,6 +811,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_FFN_SPLIT_MAX")) e->ffn_split_max = atoi(v);
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
