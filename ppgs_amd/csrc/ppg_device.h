@@ -349,7 +349,8 @@ struct AttnItem {
     int vt_off;
     int frames;
     int valid;
-    int pad0, pad1;
+    int narrow;               // 1: the item is half a query tile wide (16 queries per wave instead of 32)
+    int pad1;
 };
 
 struct AttnArgs {

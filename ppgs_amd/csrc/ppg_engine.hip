@@ -75,7 +75,7 @@ struct Plan {
     PpgPlanInfo info{};
 };
 
-void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads) {
+void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads, bool narrow_tiles) {
     plan->groups.clear();
     const int total = plan->info.tokens;
     size_t w = 0;
@@ -90,11 +90,20 @@ void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads) {
             win.vt_off -= base_vt;
             const int wi = (int)grp.windows.size();
             for (int k = 0; k < round_up(win.frames, 16) / 16; ++k) grp.blk_win.push_back(wi);
-            for (int q0 = 0; q0 < win.frames; q0 += qtile)
-                grp.items.push_back(AttnItem{wi, q0, win.tok_off, win.vt_off, win.frames, win.valid, 0, 0});
             grp.tokens = win.tok_off + round_up(win.frames, 16);
             grp.vt_tokens = win.vt_off + round_up(win.frames, 32);
             grp.windows.push_back(win);
+        }
+        // Query tiles.  A window that fits half a tile, or whose keys are at most half the longest window's, gets
+        // tiles of half the width (attn_mixed_kernel): the latter run last, on a chip the long items no longer
+        // fill, and a wave's time is its queries x the window's keys.
+        int longest = 0;
+        for (const PpgWindow& win : grp.windows) longest = std::max(longest, win.valid);
+        for (int wi = 0; wi < (int)grp.windows.size(); ++wi) {
+            const PpgWindow& win = grp.windows[wi];
+            const int narrow = narrow_tiles && (2 * win.valid <= longest || win.frames <= qtile / 2);
+            for (int q0 = 0; q0 < win.frames; q0 += narrow ? qtile / 2 : qtile)
+                grp.items.push_back(AttnItem{wi, q0, win.tok_off, win.vt_off, win.frames, win.valid, narrow, 0});
         }
         // Launch order = item order: longest first (keys actually visited; the
         // causal flag only shortens early query tiles, which keeps this order a
@@ -256,6 +265,7 @@ struct PpgEngine {
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool attn_xcd = true;    // attention items interleaved so that the query tiles of one (window, head) share an XCD's L2 (PPGS_AMD_ATTN_XCD=0: plain longest-first order)
+    bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
@@ -478,7 +488,7 @@ int group_count(const PpgEngine* e, int tokens) {
 }
 
 size_t finish_plan(const PpgEngine* e, Plan* p) {
-    split_groups(p, group_count(e, p->info.tokens), ppg::attn_query_tile(e->head_dim), e->attn_xcd ? e->cfg.heads : 0);
+    split_groups(p, group_count(e, p->info.tokens), ppg::attn_query_tile(e->head_dim), e->attn_xcd ? e->cfg.heads : 0, e->attn_narrow && e->head_dim == 128);
     size_t off = 0;
     for (PlanGroup& grp : p->groups) {
         grp.ws_offset = off;
@@ -812,6 +822,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);

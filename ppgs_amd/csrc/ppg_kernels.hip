@@ -1285,9 +1285,8 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
 // matching key order of V^T is produced by the QKV epilogue.  Row max/sum
 // over keys = per-lane partials + shuffles over the 4 lane groups.
 // ---------------------------------------------------------------------------
-template <class P, int NTQ, int DH>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <class P, int NTQ, int DH, int NW>
+__device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& item, const int head, char* smem) {
     constexpr int ROWK = DH * P::kBytes;            // K tile row bytes
     constexpr int DG = ROWK / 64;                   // K-groups over head dim
     constexpr int KT = 16384 / ROWK;                // keys per tile
@@ -1301,16 +1300,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15;
     const int g = lane >> 4;
-    // One launch index over (item, head), heads innermost: the items arrive longest first, and with a
-    // 2-D grid the whole first head (long AND short items) was dispatched before the second head's
-    // long items -- 64 of those then started 18 us into a 38 us launch (tools/attn_timeline.py).
-    const int item_index = blockIdx.x / a.heads;
-    const AttnItem item = a.items[item_index];
     const struct { int tok_off, vt_off, frames, valid; } w = {item.tok_off, item.vt_off, item.frames, item.valid};
 #ifdef PPG_ATTN_TIMING
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole chip
 #endif
-    const int head = blockIdx.x - item_index * a.heads;
     const int qw0 = item.q0 + wave * 16 * NTQ;      // first query of this wave
 
     // Q fragments
@@ -1329,7 +1322,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     }
 
     int kend = w.valid;                              // keys >= valid are masked
-    if (a.causal) kend = min(kend, item.q0 + 64 * NTQ);
+    if (a.causal) kend = min(kend, item.q0 + NW * 16 * NTQ);
     const int ntiles = (kend + KT - 1) / KT;
 
     const char* kbase = a.qk + (size_t)w.tok_off * a.qk_ld_bytes + ((size_t)a.H + (size_t)head * DH) * P::kBytes;
@@ -1339,10 +1332,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     // K runs one tile ahead of V: the scores of tile kt+1 are computed while
     // the softmax of tile kt runs (see the loop).
     auto stage_k = [&](int kt) {
-        stage_tile<KT, ROWK, 4>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, smem + (kt & 1) * 16384, wave, lane);
+        stage_tile<KT, ROWK, NW>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, smem + (kt & 1) * 16384, wave, lane);
     };
     auto stage_v = [&](int kt) {
-        stage_tile<DH, ROWV, 4>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, smem + 32768 + (kt & 1) * 16384, wave, lane);
+        stage_tile<DH, ROWV, NW>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, smem + 32768 + (kt & 1) * 16384, wave, lane);
     };
 
     f32x4 oacc[DB][NTQ];
@@ -1382,6 +1375,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     //   piece 0: mask, row max (lane partial + shuffles over the 4 lane groups)
     //   piece 1: rescale of the running sum and of O
     //   piece 2 + kb: exponentials of key block kb, packed as the PV B fragment
+    // keys below key_limit[t] + 4 g count for the lane's query of block t (padding mask, causal diagonal)
+    int key_limit[NTQ];
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t)
+        key_limit[t] = (a.causal ? min(w.valid, qw0 + 16 * t + idx + 1) : w.valid) - 4 * g;
     constexpr int PPT = 2 + KB;
     constexpr int NPIECE = NTQ * PPT;
     const float c = a.scale_log2e;
@@ -1391,14 +1389,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         constexpr int t = j / PPT, r = j % PPT;
         if constexpr (r == 0) {
             if (need_mask) {
-                const int tq = qw0 + 16 * t + idx;
+                // the lane's keys of the tile are 16 kb + e + (kt KT + 4 g): one subtraction, then constants
+                // against it (written out per key, the compiler hoists the 16 key indices above this branch
+                // and every tile pays for them)
+                const int rel = key_limit[t] - kt * KT;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int key = kt * KT + kb * 16 + 4 * g + e;
-                        if (key >= w.valid || (a.causal && key > tq)) s[kb][t][e] = -INFINITY;
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (kb * 16 + e >= rel) s[kb][t][e] = -INFINITY;
             }
             float mx = max3(s[0][t][0], s[0][t][1], s[0][t][2]);
             mx = max3(mx, s[0][t][3], mrun[t]);
@@ -1448,7 +1447,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
 
 #ifdef PPG_ATTN_TIMING
     auto stamp = [&](int kt, int k) {
-        if (a.dbg && blockIdx.x == 0 && lane == 0 && kt >= 2 && kt < 4)
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && wave < 4 && kt >= 2 && kt < 4)
             a.dbg[(wave * 2 + (kt - 2)) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
 #else
@@ -1524,6 +1523,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
         rec[3] = hwid;
     }
 #endif
+}
+
+// One launch index over (item, head), heads innermost: the items arrive longest first, and with a
+// 2-D grid the whole first head (long AND short items) was dispatched before the second head's
+// long items -- 64 of those then started 18 us into a 38 us launch (tools/attn_timeline.py).
+template <class P, int NTQ, int DH>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int item_index = blockIdx.x / a.heads;
+    const AttnItem item = a.items[item_index];
+    attn_body<P, NTQ, DH, 4>(a, item, blockIdx.x - item_index * a.heads, smem);
+}
+// Head dimension 128 with query tiles of two widths: 128 queries (32 per wave), or 64 (16 per wave) for the windows
+// the planner marks narrow: windows that fit one narrow tile, and the short windows of a batch, which run last
+// (longest first) on a chip the long ones no longer fill -- a wave's time is its queries x the window's keys, so
+// half the queries per wave on twice the workgroups shortens that tail (32 x 1000 frames: 10.4 -> 8.6 us of 32).
+// (Workgroups of 8 waves / 256 queries, which halve the K and V^T bytes streamed, measured slower: 26 vs 24 us per
+// long item -- the kernel is bound by the instructions its SIMDs issue, not by the tile traffic.)
+template <class P>
+__global__ __launch_bounds__(256, 2) void attn_mixed_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int item_index = blockIdx.x / a.heads;
+    const AttnItem item = a.items[item_index];
+    const int head = blockIdx.x - item_index * a.heads;
+    if (item.narrow) attn_body<P, 1, 128, 4>(a, item, head, smem);
+    else attn_body<P, 2, 128, 4>(a, item, head, smem);
 }
 
 template <class P, int NT, int NB, int EPI>
@@ -1623,7 +1648,7 @@ hipError_t launch_ffn_p(const FfnArgs& a, int nt, hipStream_t s) {
 template <class P>
 hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
     if (head_dim == 128) {
-        hipLaunchKernelGGL((attn_kernel<P, 2, 128>), dim3(nitems * heads), dim3(256), 65536, s, a);
+        hipLaunchKernelGGL(attn_mixed_kernel<P>, dim3(nitems * heads), dim3(256), 65536, s, a);
     } else if (head_dim == 256) {
         hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems * heads), dim3(256), 65536, s, a);
     } else {

@@ -283,6 +283,27 @@ def test_random_ragged_batches_vs_oracle():
         assert np.abs(out - ref).max() < FP32_TOL, (T, lengths)
 
 
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_attention_tiles_of_two_widths(monkeypatch, precision, causal):
+    """A batch whose windows span 30 .. 500 keys: the planner gives the short ones
+    half-width query tiles (16 queries per wave) next to the full-width tiles of the
+    long ones.  Same result as with one width everywhere and as the oracle."""
+    lengths = [1000, 1000, 230, 129, 64, 30]
+    gen = torch.Generator().manual_seed(31)
+    feats = torch.randn(len(lengths), 80, 1000, generator=gen).half()
+    state = W.seeded_state_dict(seed=1234)
+    mixed = E.Engine(state, 0, precision, causal)
+    monkeypatch.setenv('PPGS_AMD_ATTN_NARROW', '0')
+    uniform = E.Engine(state, 0, precision, causal)
+    monkeypatch.delenv('PPGS_AMD_ATTN_NARROW')
+    a, b = run(mixed, feats, lengths), run(uniform, feats, lengths)
+    tol = TOL[precision]
+    assert np.isfinite(a).all() and np.abs(a - b).max() < tol
+    ref = O.from_features(state, feats, lengths, is_causal=causal).numpy()
+    assert np.abs(a - ref).max() < tol
+
+
 def test_unfused_ffn_path_agrees(monkeypatch):
     monkeypatch.setenv('PPGS_AMD_FFN_UNFUSED', '1')
     state = W.seeded_state_dict(seed=1234)
