@@ -391,3 +391,55 @@ struct GatherArgs {
     char* qk_slack;           // the rows behind the last token of the q|k buffer
     int qk_slack_bytes;       // multiple of 16
 };
+
+// Window of a token row (the planner numbers rows window by window, every window padded to 16 rows)
+struct TokMeta {
+    int w;       // window index or -1
+    int tt;      // window-relative position
+    int frames;  // Tc
+    int valid;   // mask length
+};
+
+__device__ __forceinline__ TokMeta tok_meta(const int* blk_win, const PpgWindow* win, int m, int M) {
+    TokMeta t;
+    t.w = -1; t.tt = 0; t.frames = 0; t.valid = 0;
+    if (m < M) {
+        const int w = blk_win[m >> 4];
+        if (w >= 0) {
+            t.w = w;
+            t.tt = m - win[w].tok_off;
+            t.frames = win[w].frames;
+            t.valid = win[w].valid;
+        }
+    }
+    return t;
+}
+
+// ppg_head32.hip: window gather + input convolution + layer 0's Q/K/V projection of a 160-token tile
+struct Head32Args {
+    const void* feats;        // (B, C, T) fp16 or fp32
+    int dtype;                // PPG_DTYPE_*
+    int C;                    // <= 96
+    int T;
+    int overlap;
+    const char* win_img;      // input convolution as A fragments [wave][rb][30 K-steps = 5 taps x 6 channel blocks] (+ 1 pad)
+    const float* b_in;
+    const float* pe;          // [max_positions][H]
+    float* X;                 // fp32 residual stream out, X32 order
+    const char* wq_img;       // layer 0's in_proj (as Layer32Args::wq_img)
+    const float* bq;
+    char* qk_out;
+    char* vt_out;
+    int vt_ld;
+    const int* blk_win;
+    const PpgWindow* win;
+    int M;
+    int H;                    // 256
+    int tiles;                // workgroups 0 .. tiles - 1 compute; the rest keep the scratch areas finite (see GatherArgs)
+    int nwin;
+    int vt_rows;
+    int vt_tokens;
+    char* qk_slack;
+    int qk_slack_bytes;
+    int debug_mode;           // timing experiments (wrong results): 1 no convolution, 2 no Q/K/V, 4 no gather
+};

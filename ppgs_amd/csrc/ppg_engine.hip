@@ -265,6 +265,8 @@ struct PpgEngine {
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool attn_xcd = true;    // attention items interleaved so that the query tiles of one (window, head) share an XCD's L2 (PPGS_AMD_ATTN_XCD=0: plain longest-first order)
+    bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
+    char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
@@ -823,6 +825,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
+    if (!e->layer32 || H != 256 || e->Cp != 96 || !e->qkv_fused) e->head32 = false;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
@@ -855,6 +859,24 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
                            &e->w_in);
         if (rc) return rc;
         if ((rc = upload_f32(E, wts->input_bias, H, 0, &e->b_in))) return rc;
+    }
+    if (e->head32) {
+        // the same convolution as A fragments for ppg_head32.hip: [wave][rb][K-step = tap x 16-channel block],
+        // lane (row l & 31 of the block in accumulator order phi, channels 8 (l >> 5) .. + 7), one zero fragment behind
+        const float* w = wts->input_weight;
+        const int RB = H / 128, KSI = 5 * e->Cp / 16, frags = 4 * RB * KSI;
+        auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+        rc = upload_matrix(E, (frags + 1) * 64, 8, (frags + 1) * 64, 8,
+                           [&](int r, int j) {
+                               const int f = r >> 6, ln = r & 63;
+                               if (f >= frags) return 0.f;
+                               const int ks = f % KSI, rb = (f / KSI) % RB, wv = f / (KSI * RB);
+                               const int tap = ks / (e->Cp / 16), c = 16 * (ks % (e->Cp / 16)) + 8 * (ln >> 5) + j;
+                               const int h = 32 * RB * wv + 32 * rb + phi(ln & 31);
+                               return c < C ? w[((size_t)h * C + c) * 5 + tap] : 0.f;
+                           },
+                           &e->win_img);
+        if (rc) return rc;
     }
     {   // out-conv W'[n][tap*H + c] = w[n][c][tap], rows padded to 48
         const float* w = wts->output_weight;
@@ -1049,7 +1071,22 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     const int lnt = forced ? e->lin_nt : std::min(nt, 2);
     const int lnt_ln = forced ? e->lin_nt : 1;
 
-    {
+    const bool use32 = e->layer32 && e->ffn_fused && ws.ffn_splits == 1;
+    const bool head = use32 && e->head32;
+    if (head) {
+        Timed t(e, PPG_K_INCONV, s);
+        Head32Args a{};
+        a.feats = features; a.dtype = feature_dtype; a.C = c.input_channels; a.T = frames; a.overlap = c.chunk_overlap;
+        a.win_img = e->win_img; a.b_in = e->b_in; a.pe = e->pe; a.X = X;
+        a.wq_img = e->layers[0].wq_img; a.bq = e->layers[0].bqkv; a.qk_out = qk; a.vt_out = vt; a.vt_ld = ws.vt_ld;
+        a.blk_win = grp.d_blk; a.win = grp.d_win; a.M = M; a.H = H;
+        a.tiles = (M + ppg::layer32_tokens(H) - 1) / ppg::layer32_tokens(H);
+        a.nwin = (int)grp.windows.size(); a.vt_rows = H; a.vt_tokens = grp.vt_tokens;
+        a.qk_slack = qk + (size_t)M * 2 * H * e->sz; a.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
+        if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) a.debug_mode = atoi(v);
+        LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
+    }
+    if (!head) {
         Timed t(e, PPG_K_GATHER, s);
         GatherArgs g{};
         g.feats = features; g.dtype = feature_dtype; g.C = c.input_channels; g.T = frames;
@@ -1067,8 +1104,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.X = X; a.Xb = Xb; a.v_start = INT_MAX; a.taps = 1;
         return a;
     };
-    const bool use32 = e->layer32 && e->ffn_fused && ws.ffn_splits == 1;
-    {
+    if (!head) {
         Timed t(e, PPG_K_INCONV, s);
         LinearArgs a = base_args();
         a.x_tiled = use32;
@@ -1080,7 +1116,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, lnt, a, H / 256, s), "in-conv");
     }
     const int hg = H / e->KG;   // K-groups of a hidden-wide row
-    bool qkv_done = false;   // this layer's Q/K/V came out of the previous layer's FFN kernel
+    bool qkv_done = head;    // this layer's Q/K/V came out of the previous layer's FFN kernel (layer 0's: out of the head kernel)
     for (int l = 0; l < c.num_layers; ++l) {
         const DevLayer& d = e->layers[l];
         if (!qkv_done) {

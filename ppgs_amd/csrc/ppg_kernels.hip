@@ -12,28 +12,6 @@ namespace {
 
 constexpr float kLnEps = 1e-5f;
 
-struct TokMeta {
-    int w;       // window index or -1
-    int tt;      // window-relative position
-    int frames;  // Tc
-    int valid;   // mask length
-};
-
-__device__ __forceinline__ TokMeta tok_meta(const int* blk_win, const PpgWindow* win, int m, int M) {
-    TokMeta t;
-    t.w = -1; t.tt = 0; t.frames = 0; t.valid = 0;
-    if (m < M) {
-        const int w = blk_win[m >> 4];
-        if (w >= 0) {
-            t.w = w;
-            t.tt = m - win[w].tok_off;
-            t.frames = win[w].frames;
-            t.valid = win[w].valid;
-        }
-    }
-    return t;
-}
-
 // Software-pipelined LDS fragment stream for one wave per SIMD: D reads are
 // kept in flight; fragment I is consumed (its MFMAs issued) and its ring slot
 // immediately re-armed with fragment I + D.

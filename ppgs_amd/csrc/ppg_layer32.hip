@@ -28,116 +28,9 @@
 // so a lane's 16 values of a block are 64 contiguous bytes of an fp32 row.  Packed to
 // 16 bits, registers (q = 2s, 2s+1) are exactly the B fragment of K-step s: the
 // accumulator of one GEMM is the operand of the next after ONE ds_write_b128.
-#include "ppg_device.h"
-#include "ppg_launch.h"
-
-#include <type_traits>
-#include <utility>
+#include "ppg_layer32.h"
 
 namespace {
-
-constexpr float kLnEps32 = 1e-5f;
-constexpr int HC = 128;               // hidden rows of the FFN per chunk (4 waves x 32)
-
-// Geometry of a hidden width: wave w owns features 32 RB w .. + 32 RB - 1 (RB 32-row blocks)
-// of every HIDT-wide result; the workgroup's TBN token blocks of 32 keep the accumulators
-// (RB * TBN + TBN blocks of 16 registers) inside the 256 AGPRs.
-template <int HIDT>
-struct Geo {
-    static_assert(HIDT == 256 || HIDT == 512, "hidden width");
-    static constexpr int RB = HIDT / 128;
-    static constexpr int KS = HIDT / 16;            // 16-wide K-steps of a token-panel row
-    static constexpr int KH = KS / 16;              // halves of 16 K-steps (one register set of fragments each)
-    static constexpr int TBN = HIDT == 256 ? 5 : 3;
-    static constexpr int TOKS = 32 * TBN;
-    // LDS map (bytes)
-    static constexpr int L_ACT = 0;                             // token panel: fragments [tb][KS] of 1 KiB
-    static constexpr int L_H = TBN * KS * 1024;                 // h of one chunk: fragments [tb][8]
-    static constexpr int L_LNP1 = L_H + TBN * 8 * 1024;         // [bo | gamma1 | beta1]
-    static constexpr int L_LNP2 = L_LNP1 + 3 * HIDT * 4;        // [b2 | gamma2 | beta2]
-    static constexpr int L_BQ = L_LNP2 + 3 * HIDT * 4;          // next layer's in_proj bias
-    static constexpr int L_STATS = L_BQ + 3 * HIDT * 4;         // LayerNorm partial sums [2][4 waves][TOKS]
-    static constexpr int L_B1 = L_STATS + 2 * 4 * TOKS * 4;     // b1, F floats
-};
-
-__device__ __forceinline__ uint32_t lds_addr32(const void* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
-template <int OFF>
-__device__ __forceinline__ void ds_read128(u32x4& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait32(u32x4& r) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-// 1 KiB fragment -> registers: wave-uniform base in SGPRs + lane * 16 + immediate
-template <int OFF>
-__device__ __forceinline__ void gload128(u32x4& dst, uint32_t voff, const char* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
-}
-// fragment k of a run of fragments at `base` (the immediate reaches 4 KiB)
-template <int K>
-__device__ __forceinline__ void gload_frag(u32x4& dst, uint32_t voff, const char* base) {
-    gload128<(K % 4) * 1024>(dst, voff, base + (K / 4) * 4096);
-}
-// every load issued so far has landed; the registers are tied so no use moves above
-template <int COUNT>
-__device__ __forceinline__ void vm_wait_all(u32x4 (&r)[COUNT]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < COUNT; ++i) asm volatile("" : "+v"(r[i]));
-    __builtin_amdgcn_sched_barrier(0);
-}
-// 16-byte global -> LDS DMA, per-lane source offset (the attention output's rows)
-__device__ __forceinline__ void glds16(const char* uniform_base, uint32_t lane_off, uint32_t lds_wave_addr) {
-    const uint64_t b = reinterpret_cast<uint64_t>(uniform_base);
-    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(lane_off), "s"(base), "s"(__builtin_amdgcn_readfirstlane(lds_wave_addr)) : "memory", "m0");
-}
-
-// Stream of N LDS fragments, D reads in flight; fragment of step i at byte offset
-// OFFS::at(i) from b0 (b1 = b0 + 64 KiB covers the offsets the 16-bit field cannot)
-template <class OFFS, int I, int N, int D, class USE>
-__device__ __forceinline__ void stream_step(u32x4 (&ring)[D], uint32_t b0, uint32_t b1, USE& use) {
-    if constexpr (I < N) {
-        lgkm_wait32<(N - 1 - I < D - 1) ? (N - 1 - I) : (D - 1)>(ring[I % D]);
-        use(std::integral_constant<int, I>{}, ring[I % D]);
-        if constexpr (I + D < N) {
-            constexpr int off = OFFS::at(I + D);
-            if constexpr (off < 65536) ds_read128<off>(ring[I % D], b0); else ds_read128<off - 65536>(ring[I % D], b1);
-        }
-        stream_step<OFFS, I + 1, N, D>(ring, b0, b1, use);
-    }
-}
-template <class OFFS, int I, int N, int D>
-__device__ __forceinline__ void stream_prime(u32x4 (&ring)[D], uint32_t b0, uint32_t b1) {
-    if constexpr (I < D && I < N) {
-        constexpr int off = OFFS::at(I);
-        if constexpr (off < 65536) ds_read128<off>(ring[I], b0); else ds_read128<off - 65536>(ring[I], b1);
-        stream_prime<OFFS, I + 1, N, D>(ring, b0, b1);
-    }
-}
-template <class OFFS, int N, int D, class USE>
-__device__ __forceinline__ void stream(uint32_t b0, uint32_t b1, USE use) {
-    u32x4 ring[D];
-    stream_prime<OFFS, 0, N, D>(ring, b0, b1);
-    stream_step<OFFS, 0, N, D>(ring, b0, b1, use);
-}
-// Panel stream: step i = (K0 + i / NTB, TB0 + i % NTB) reads panel fragment tb * KS + ks
-template <int KS, int K0, int TB0, int NTB>
-struct OffPanel { static constexpr int at(int i) { return ((TB0 + i % NTB) * KS + K0 + i / NTB) * 1024; } };
-// h stream: step i = (ks = i / TBN, tb = i % TBN) reads h fragment tb * 8 + ks
-template <int TBN>
-struct OffH { static constexpr int at(int i) { return ((i % TBN) * 8 + i / TBN) * 1024; } };
-
-__device__ __forceinline__ float pair_sum(float v) {          // lanes l and l + 32
-    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
 
 template <class P, int HIDT, bool QKV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void layer32_kernel(Layer32Args a) {
@@ -497,109 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(5);
 
     if constexpr (QKV) {
-        // ---- the next layer's Q/K/V projection on x2 ------------------------------------------
-        // 3 RB steps of one 32-row block each: Q and K features of this wave (row-major stores, a lane
-        // owns 16 consecutive features of its token) and its V features with the MFMA operands swapped,
-        // so that the accumulator comes out transposed for V^T (a lane owns one V^T row and 16 tokens).
-        // Every step takes KH half-steps of 16 W fragments (image order [wave][step][ks]); the two register
-        // sets alternate: the next half-step's fragments travel under this one's MFMAs.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                       // x2 panel complete
-        const float* bq = reinterpret_cast<const float*>(smem + G::L_BQ);
-        // transposed-V columns of the wave-uniform 16-token halves of every token block
-        int vcol[TB][2];
-        bool valigned[TB];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int mb = m0 + 32 * t + 16 * h;
-                vcol[t][h] = -1;
-                if (mb < a.M) {
-                    const int w = a.blk_win[mb >> 4];
-                    if (w >= 0) {
-                        const int ttb = mb - a.win[w].tok_off;
-                        vcol[t][h] = a.win[w].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
-                    }
-                }
-            }
-            valigned[t] = vcol[t][0] >= 0 && vcol[t][1] == vcol[t][0] + 4 && (vcol[t][0] & 31) == 0;
-        }
-        const char* wq = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
-        f32x16 acc[TB];
-        auto half_step = [&](auto hs_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
-            constexpr int HS = decltype(hs_tag)::value;
-            constexpr int STEP = HS / KH, kh = HS % KH;
-            constexpr int KIND = STEP / RB, RBI = STEP % RB;        // 0 Q, 1 K, 2 V; row block inside the wave's features
-            constexpr bool SWAP = KIND == 2;
-            constexpr bool LAST = HS + 1 == 3 * RB * KH;
-            const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
-            stream<OffPanel<KS, 16 * kh, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / TB, tb = i % TB;
-                if constexpr (ks == 0 && kh == 0) acc[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
-                else acc[tb] = SWAP ? P::mma32(bf, cur[ks], acc[tb]) : P::mma32(cur[ks], bf, acc[tb]);
-                // the next half-step's fragments: issued in the first three fifths of the stream so that ...
-                if constexpr (!LAST && i % 3 == 0 && i / 3 < 16) gload_frag<i / 3>(nxt[i / 3], voff, nbase);
-            });
-            // ... they have landed here: the epilogue below is ordinary compiler code, which may move or
-            // spill registers it believes ready (an asm load's destination must be waited for before that)
-            if constexpr (!LAST) vm_wait_all(nxt);
-            if constexpr (kh + 1 < KH) return;
-            if constexpr (!SWAP) {
-                // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh .. + 15
-                constexpr int n0 = HIDT * KIND + 32 * RBI;
-                float4 b4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bq + n0 + fbase + 16 * hh + 4 * q);
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    const int m = m0 + 32 * t + tok;
-                    if (m >= a.M) continue;
-                    char* dst = a.qk_out + ((size_t)m * 2 * HIDT + n0 + fbase + 16 * hh) * 2;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
-                        *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{
-                            P::pack2(acc[t][8 * s2 + 0] + ba.x, acc[t][8 * s2 + 1] + ba.y), P::pack2(acc[t][8 * s2 + 2] + ba.z, acc[t][8 * s2 + 3] + ba.w),
-                            P::pack2(acc[t][8 * s2 + 4] + bb.x, acc[t][8 * s2 + 5] + bb.y), P::pack2(acc[t][8 * s2 + 6] + bb.z, acc[t][8 * s2 + 7] + bb.w)};
-                    }
-                }
-            } else {
-                // V: lane = V^T row fbase + 32 RBI + (l & 31) (natural feature pair_row(row): attn_kernel's
-                // tile order), registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of
-                // every 32-token group of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
-                const int vrow = fbase + 32 * RBI + tok;
-                const float bv = bq[2 * HIDT + pair_row(vrow)];
-                char* rowp = a.vt_out + (size_t)vrow * a.vt_ld * 2;
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    if (valigned[t]) {        // the block is one 32-token group: (q, q + 2) are 8 consecutive columns
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-                            *reinterpret_cast<u32x4*>(rowp + (size_t)(vcol[t][0] + 16 * s2 + 8 * hh) * 2) = u32x4{
-                                P::pack2(acc[t][4 * s2 + 0] + bv, acc[t][4 * s2 + 1] + bv), P::pack2(acc[t][4 * s2 + 2] + bv, acc[t][4 * s2 + 3] + bv),
-                                P::pack2(acc[t][4 * (s2 + 2) + 0] + bv, acc[t][4 * (s2 + 2) + 1] + bv), P::pack2(acc[t][4 * (s2 + 2) + 2] + bv, acc[t][4 * (s2 + 2) + 3] + bv)};
-                    } else {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            if (vcol[t][h] < 0) continue;
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
-                                const int q = 2 * h + s2;
-                                *reinterpret_cast<uint2*>(rowp + (size_t)(vcol[t][h] + 8 * (2 * s2 + hh)) * 2) = make_uint2(
-                                    P::pack2(acc[t][4 * q + 0] + bv, acc[t][4 * q + 1] + bv), P::pack2(acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv));
-                            }
-                        }
-                    }
-                }
-            }
-        };
-        // (half-step 0's fragments arrived in set 1 with the last FFN chunk)
-        [&]<int... S>(std::integer_sequence<int, S...>) {
-            ((S % 2 == 0 ? half_step(std::integral_constant<int, S>{}, w1f, w2f)
-                         : half_step(std::integral_constant<int, S>{}, w2f, w1f)), ...);
-        }(std::make_integer_sequence<int, 3 * RB * KH>{});
+        qkv_tail<P, HIDT>(a, smem, m0, w1f, w2f);
         pstamp(6);
     }
 }

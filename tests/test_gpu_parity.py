@@ -383,6 +383,38 @@ def test_fused_layer_kernel_vs_oracle_and_unfused(monkeypatch, precision):
         assert np.allclose(out[b, :, n:], 1 / 40)
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('case', ['touching_windows', 'chunked_fp32_features'])
+def test_head_kernel_vs_three_launches(monkeypatch, precision, case):
+    """Gather + input convolution + layer 0's Q/K/V in one kernel (ppg_head32.hip) against the
+    gather / in-conv / QKV launches it replaces and against the oracle.  'touching_windows':
+    48 windows of exactly 160 rows (10 blocks of 16, no padding rows between them), so the
+    convolution's taps at every window edge would reach a neighbour's live rows -- the per-lane
+    tap mask -- with ragged valid lengths; 'chunked_fp32_features': 1200-frame items (windows
+    with replicate padding on the left, 500 / 500 / 300 frames) given as fp32 features."""
+    gen = torch.Generator().manual_seed(23)
+    if case == 'touching_windows':
+        frames = 160
+        lengths = [160] * 8 + torch.randint(1, 161, (40,), generator=gen).tolist()
+        feats = torch.randn(len(lengths), 80, frames, generator=gen).half()
+    else:
+        frames = 1200
+        lengths = [1200, 1200, 1111, 1200, 640, 1200, 1200, 77]
+        feats = torch.randn(len(lengths), 80, frames, generator=gen)
+    _, info = E.plan_windows(len(lengths), frames, lengths)
+    assert info.tokens > 6144
+    state = W.seeded_state_dict(seed=1234)
+    fused = E.Engine(state, 0, precision)
+    monkeypatch.setenv('PPGS_AMD_HEAD32', '0')
+    three = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_HEAD32')
+    a, b = run(fused, feats, lengths), run(three, feats, lengths)
+    assert np.isfinite(a).all() and not np.array_equal(a, b)       # (two different kernels ran)
+    assert np.abs(a - b).max() < TOL[precision]
+    ref = O.from_features(state, feats.float(), torch.tensor(lengths)).numpy()
+    assert np.abs(a - ref).max() < TOL[precision]
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('shape', ['ragged', 'odd_blocks', 'layer32'])
 def test_poisoned_workspace(precision, shape):
