@@ -442,4 +442,5 @@ struct Head32Args {
     char* qk_slack;
     int qk_slack_bytes;
     int debug_mode;           // timing experiments (wrong results): 1 no convolution, 2 no Q/K/V, 4 no gather
+    unsigned long long* dbg;  // PPGS_AMD_H32_TIMING=1: s_memtime stamps of workgroup 0, [wave][16]
 };

@@ -276,6 +276,7 @@ struct PpgEngine {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     unsigned long long* ffn_dbg = nullptr;
+    unsigned long long* head_dbg = nullptr;
     unsigned long long* attn_dbg = nullptr;  // PPGS_AMD_ATTN_TIMING (PPG_ATTN_TIMING builds)
     unsigned long long* lin_dbg = nullptr;   // PPGS_AMD_LIN_TIMING=<kernel class> (PPG_LIN_TIMING builds): stamps of layer 0
     int lin_dbg_class = -1;
@@ -299,6 +300,17 @@ struct PpgEngine {
 
     ~PpgEngine() {
         (void)hipSetDevice(device);
+        if (head_dbg) {
+            unsigned long long h[64];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(h, head_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long* t = h + w * 16;
+                    fprintf(stderr, "head32 wave %d: gather %llu  bias+meta %llu  conv0 %llu  conv1 %llu  emit %llu  wq %llu  tail %llu | total %llu\n",
+                            w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[7] - t[0]);
+                }
+            (void)hipFree(head_dbg);
+        }
         if (ffn_dbg) {
             unsigned long long h[256];
             (void)hipDeviceSynchronize();
@@ -837,6 +849,10 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->attn_dbg), 512 + 4096 * 32));
         HIP_OK(hipMemset(e->attn_dbg, 0, 512 + 4096 * 32));
     }
+    if (getenv("PPGS_AMD_H32_TIMING")) {
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->head_dbg), 512));
+        HIP_OK(hipMemset(e->head_dbg, 0, 512));
+    }
     if (getenv("PPGS_AMD_FFN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 2048));
         HIP_OK(hipMemset(e->ffn_dbg, 0, 2048));
@@ -1072,7 +1088,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     const int lnt_ln = forced ? e->lin_nt : 1;
 
     const bool use32 = e->layer32 && e->ffn_fused && ws.ffn_splits == 1;
-    const bool head = use32 && e->head32;
+    // (one 160-token tile per workgroup: below half a chip of tiles the three launches, with their smaller workgroups, are as fast)
+    const bool head = use32 && e->head32 && 2 * ((M + ppg::layer32_tokens(H) - 1) / ppg::layer32_tokens(H)) >= e->num_cus;
     if (head) {
         Timed t(e, PPG_K_INCONV, s);
         Head32Args a{};
@@ -1084,6 +1101,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.nwin = (int)grp.windows.size(); a.vt_rows = H; a.vt_tokens = grp.vt_tokens;
         a.qk_slack = qk + (size_t)M * 2 * H * e->sz; a.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
         if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) a.debug_mode = atoi(v);
+        a.dbg = e->head_dbg;
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
     if (!head) {

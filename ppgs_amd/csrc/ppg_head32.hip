@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert((TOKS + 2 * HALO) * ROWB <= TB * 8 * 1024, "the gathered tile fits the h region");
     float* bq_lds = reinterpret_cast<float*>(smem + G::L_BQ);
 
+    auto pstamp = [&](int k) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 16 + k] = __builtin_amdgcn_s_memtime();
+    };
+    pstamp(0);
     u32x4 w1f[16], w2f[16];
     auto load16 = [&](u32x4 (&wf)[16], const char* base) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
@@ -99,27 +103,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 base = (size_t)w.item * a.C * a.T;
             }
         }
+        // every load is issued unconditionally (a dead row reads frame 0 of item 0, a padding channel re-reads the last
+        // one) and masked afterwards: predicated loads came out as 96 branches with a wait each, 51 k cycles of this
+        // kernel's 138 k
         uint32_t* dst = reinterpret_cast<uint32_t*>(rows + tid * ROWB);
-        const int C = frame >= 0 ? a.C : 0;
+        const int C = a.C;
+        const bool row_live = frame >= 0;
         const size_t off = base + (size_t)max(frame, 0);
+        float v[CP];
         if (a.dtype == PPG_DTYPE_F16) {
             const __half* src = reinterpret_cast<const __half*>(a.feats) + off;
 #pragma unroll
-            for (int cp = 0; cp < CP / 2; ++cp) {
-                const float v0 = 2 * cp < C ? __half2float(src[(size_t)(2 * cp) * a.T]) : 0.f;
-                const float v1 = 2 * cp + 1 < C ? __half2float(src[(size_t)(2 * cp + 1) * a.T]) : 0.f;
-                dst[cp] = P::pack2(v0, v1);
-            }
+            for (int c = 0; c < CP; ++c) v[c] = __half2float(src[(size_t)min(c, C - 1) * a.T]);
         } else {
             const float* src = reinterpret_cast<const float*>(a.feats) + off;
 #pragma unroll
-            for (int cp = 0; cp < CP / 2; ++cp) {
-                const float v0 = 2 * cp < C ? src[(size_t)(2 * cp) * a.T] : 0.f;
-                const float v1 = 2 * cp + 1 < C ? src[(size_t)(2 * cp + 1) * a.T] : 0.f;
-                dst[cp] = P::pack2(v0, v1);
-            }
+            for (int c = 0; c < CP; ++c) v[c] = src[(size_t)min(c, C - 1) * a.T];
         }
+#pragma unroll
+        for (int cp = 0; cp < CP / 2; ++cp)
+            dst[cp] = P::pack2(row_live && 2 * cp < C ? v[2 * cp] : 0.f, row_live && 2 * cp + 1 < C ? v[2 * cp + 1] : 0.f);
     }
+    pstamp(1);
     // layer 0's in_proj bias for the tail
     for (int i = tid; i < 3 * HID / 4; i += 256) reinterpret_cast<float4*>(bq_lds)[i] = reinterpret_cast<const float4*>(a.bq)[i];
 
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         edge[t] = bits;
     }
 
+    pstamp(2);
     // ---- 2. input convolution: y[rb][tb] = W[rows of this wave] x rows, two rounds of KSH K-steps, the fragments
     // of the wave's two row blocks in the two register sets (image order [wave][rb][KSI])
     f32x16 yacc[RB][TB];
@@ -157,13 +163,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int q = 0; q < 4; ++q)
                 pe[t][q] = *reinterpret_cast<const float4*>(a.pe + (size_t)tt[t] * HID + fbase + 32 * rb + 16 * hh + 4 * q);
     };
-    auto round = [&](auto r_tag) {
+    auto round = [&](auto r_tag, auto after_wait) {
         constexpr int R = decltype(r_tag)::value;
         // (16 fragments are fetched where KSH = 15 are used: the image carries one pad fragment at its end)
         load16(w1f, wimg + (size_t)(KSH * R) * 1024);
         load16(w2f, wimg + (size_t)(KSI + KSH * R) * 1024);
         vm_wait_all(w1f);
         vm_wait_all(w2f);
+        after_wait();
         if constexpr (R == 0) __syncthreads();               // the gathered rows are in LDS
         stream<OffIn<KSH * R, TB>, KSH * TB, 6>(rb0, rb0, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
@@ -184,11 +191,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         });
     };
-    if (!(a.debug_mode & 1)) round(std::integral_constant<int, 0>{});
+    if (!(a.debug_mode & 1)) round(std::integral_constant<int, 0>{}, [] {});
     else __syncthreads();
-    load_pe(0);                                              // lands under the second round
-    if (!(a.debug_mode & 1)) round(std::integral_constant<int, 1>{});
+    pstamp(3);
+    // (the PE rows of the first row block are requested behind the round's weight wait and land under its MFMAs)
+    if (!(a.debug_mode & 1)) round(std::integral_constant<int, 1>{}, [&] { load_pe(0); });
+    else load_pe(0);
 
+    pstamp(4);
     // ---- 3. x = live ? PE[tt] + (valid ? y + bias : 0) : 0 (as linear_kernel<EPI_INCONV>) -> X32 and the panel
     float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 4 * 256) + lane * 4;
     auto emit = [&](auto rb_tag) {
@@ -218,16 +228,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     emit(std::integral_constant<int, 0>{});
     emit(std::integral_constant<int, 1>{});
+    pstamp(5);
     // layer 0's W_qkv fragments of the tail's first half-step (not earlier: the compiler may move registers an asm
     // load has not landed in yet, and the epilogue above is its code)
     load16(w1f, a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024);
     vm_wait_all(w1f);
+    pstamp(6);
 
     // ---- 4. layer 0's Q/K/V
     Layer32Args la{};
     la.wq_img = a.wq_img; la.qk_out = a.qk_out; la.vt_out = a.vt_out; la.vt_ld = a.vt_ld;
     la.blk_win = a.blk_win; la.win = a.win; la.M = a.M; la.H = HID;
     if (!(a.debug_mode & 2)) qkv_tail<P, HID>(la, smem, m0, w1f, w2f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pstamp(7);
 }
 
 }  // namespace
