@@ -179,6 +179,12 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         constexpr bool SWAP = KIND == 2;
         constexpr bool LAST = HS + 1 == 3 * RB * KH;
         const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
+#ifdef PPG_FFN_TIMING
+        auto tstamp = [&](int k) { if (a.dbg && blockIdx.x == 0 && lane == 0 && wave == 0 && HS < 6) a.dbg[192 + HS * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#else
+        auto tstamp = [&](int) {};
+#endif
+        tstamp(0);
         stream<OffPanel<KS, 16 * kh, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
             constexpr int ks = i / TB, tb = i % TB;
@@ -189,7 +195,9 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         });
         // ... they have landed here: the epilogue below is ordinary compiler code, which may move or
         // spill registers it believes ready (an asm load's destination must be waited for before that)
+        tstamp(1);
         if constexpr (!LAST) vm_wait_all(nxt);
+        tstamp(2);
         if constexpr (kh + 1 < KH) return;
         if constexpr (!SWAP) {
             // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh .. + 15
@@ -239,6 +247,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
                 }
             }
         }
+        tstamp(3); tstamp(4); tstamp(5);
     };
     // (half-step 0's fragments arrived in set 1 with the last FFN chunk)
     [&]<int... S>(std::integer_sequence<int, S...>) {

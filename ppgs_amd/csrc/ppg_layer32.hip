@@ -76,25 +76,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     f32x16 yacc[RB][TB];
-    // parameters: every global load first, the LDS stores afterwards (one memory round trip, not three)
+    // parameters: every global load first, the LDS stores afterwards (one memory round trip, not three).  The loads
+    // are unconditional on clamped indices -- a load under `if` comes out as a branch with its own wait -- and only
+    // the LDS stores are predicated.
     {
         constexpr int NP = (3 * HIDT / 4 + 255) / 256;
         float4 p1[NP], p2[NP], pq[NP];
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int i = tid + 256 * u;
+            const int i = min(tid + 256 * u, 3 * HIDT / 4 - 1);
             const int v = i / (HIDT / 4), j = i - v * (HIDT / 4);
-            if (i < 3 * HIDT / 4) {
-                p1[u] = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
-                p2[u] = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
-                if constexpr (QKV) pq[u] = reinterpret_cast<const float4*>(a.bq)[i];
-            }
+            p1[u] = reinterpret_cast<const float4*>(v == 0 ? a.bo : (v == 1 ? a.g1 : a.e1))[j];
+            p2[u] = reinterpret_cast<const float4*>(v == 0 ? a.b2 : (v == 1 ? a.g2 : a.e2))[j];
+            if constexpr (QKV) pq[u] = reinterpret_cast<const float4*>(a.bq)[i];
         }
         constexpr int B1MAX = 8;                 // F <= 8192
         float4 pb[B1MAX];
 #pragma unroll
-        for (int u = 0; u < B1MAX; ++u)
-            if (tid + 256 * u < a.F / 4) pb[u] = reinterpret_cast<const float4*>(a.b1)[tid + 256 * u];
+        for (int u = 0; u < B1MAX; ++u) pb[u] = reinterpret_cast<const float4*>(a.b1)[min(tid + 256 * u, a.F / 4 - 1)];
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int i = tid + 256 * u;
