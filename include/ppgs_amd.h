@@ -162,6 +162,28 @@ int ppg_plan_windows(const PpgEngine* engine, int batch, int frames,
                      const int64_t* lengths_host, int legacy_mode,
                      PpgWindow* windows, int max_windows, PpgPlanInfo* info);
 
+/*
+ * The attention launch order of a batch, host only: one item per (window,
+ * query tile), in the order the workgroups are dispatched -- longest windows
+ * first, the tiles of one window `8 / gcd(8, heads)` items apart so that all
+ * of them (for one head) run on one XCD's L2, half-width tiles for the short
+ * windows of a batch (ppg_engine.hip: split_groups).  `engine` may be NULL:
+ * then chunk 500 / overlap 50, head dimension 128, `heads` as given, one
+ * launch group.  Writes up to max_items entries and returns the total count,
+ * or a negative error.
+ */
+typedef struct PpgAttentionItem {
+    int32_t window;          /* index into the COMPUTED windows (tok_off >= 0) in plan order */
+    int32_t q0;              /* first query row of the tile, window-relative                   */
+    int32_t queries;         /* tile width: 128 or 64 (head dimension 128), 64 (256)           */
+    int32_t frames;          /* rows of the window                                             */
+    int32_t valid;           /* keys that count (the rest is padding)                          */
+    int32_t narrow;          /* 1: half-width tile                                             */
+} PpgAttentionItem;
+int ppg_plan_attention_items(const PpgEngine* engine, int batch, int frames,
+                             const int64_t* lengths_host, int legacy_mode, int heads,
+                             PpgAttentionItem* items, int max_items);
+
 /* Workspace (device bytes) ppg_encode needs for this batch. */
 int ppg_workspace_bytes(const PpgEngine* engine, int batch, int frames,
                         const int64_t* lengths_host, int legacy_mode,

@@ -1020,6 +1020,32 @@ int ppg_plan_windows(const PpgEngine* engine, int batch, int frames, const int64
     return n;
 }
 
+int ppg_plan_attention_items(const PpgEngine* engine, int batch, int frames, const int64_t* lengths,
+                             int legacy_mode, int heads, PpgAttentionItem* items, int max_items) {
+    Plan plan;
+    const int chunk = engine ? engine->cfg.chunk_length : 500;
+    const int overlap = engine ? engine->cfg.chunk_overlap : 50;
+    const int maxpos = engine ? engine->cfg.max_positions : 5000;
+    const int head_dim = engine ? engine->head_dim : 128;
+    const int qt = ppg::attn_query_tile(head_dim);
+    if (engine) heads = engine->cfg.heads;
+    if (heads <= 0) return fail(PPG_EINVAL, "heads=%d", heads);
+    int rc = build_plan(chunk, overlap, maxpos, batch, frames, lengths, legacy_mode, qt, &plan);
+    if (rc) return rc;
+    if (engine) finish_plan(engine, &plan);
+    else split_groups(&plan, 1, qt, heads, head_dim == 128);
+    int n = 0, wbase = 0;
+    for (const PlanGroup& grp : plan.groups) {
+        for (const AttnItem& it : grp.items) {
+            if (items && n < max_items)
+                items[n] = PpgAttentionItem{wbase + it.window, it.q0, it.narrow ? qt / 2 : qt, it.frames, it.valid, it.narrow};
+            ++n;
+        }
+        wbase += (int)grp.windows.size();
+    }
+    return n;
+}
+
 int ppg_workspace_bytes(const PpgEngine* engine, int batch, int frames, const int64_t* lengths,
                         int legacy_mode, size_t* bytes) {
     if (!engine || !bytes) return fail(PPG_EINVAL, "null argument");

@@ -52,6 +52,11 @@ class PpgWindow(ctypes.Structure):
         'out_frame', 'tok_off', 'vt_off', 'pad0', 'pad1')]
 
 
+class PpgAttentionItem(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        'window', 'q0', 'queries', 'frames', 'valid', 'narrow')]
+
+
 class PpgPlanInfo(ctypes.Structure):
     _fields_ = [
         ('num_windows', ctypes.c_int32), ('skipped_windows', ctypes.c_int32),
@@ -73,6 +78,9 @@ SYMBOLS = {
     'ppg_plan_windows': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _I64P, ctypes.c_int,
         ctypes.POINTER(PpgWindow), ctypes.c_int, ctypes.POINTER(PpgPlanInfo)]),
+    'ppg_plan_attention_items': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _I64P, ctypes.c_int, ctypes.c_int,
+        ctypes.POINTER(PpgAttentionItem), ctypes.c_int]),
     'ppg_workspace_bytes': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _I64P, ctypes.c_int,
         ctypes.POINTER(ctypes.c_size_t)]),
@@ -189,6 +197,17 @@ def plan_windows(batch, frames, lengths, legacy_mode=False, engine=None):
         handle, batch, frames, arr, int(legacy_mode), windows, count,
         ctypes.byref(info)))
     return list(windows)[:count], info
+
+
+def plan_attention_items(batch, frames, lengths, legacy_mode=False, heads=config.ATTENTION_HEADS, engine=None):
+    """Host-only: the attention work items of a batch in launch order (ppg_plan_attention_items)."""
+    lib = library()
+    arr = _lengths_array(lengths, batch)
+    handle = engine._handle if engine is not None else None
+    count = _check(lib.ppg_plan_attention_items(handle, batch, frames, arr, int(legacy_mode), heads, None, 0))
+    items = (PpgAttentionItem * max(count, 1))()
+    _check(lib.ppg_plan_attention_items(handle, batch, frames, arr, int(legacy_mode), heads, items, count))
+    return list(items)[:count]
 
 
 class Engine:

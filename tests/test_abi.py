@@ -2,6 +2,7 @@
 declares, and its host-only planner agrees with the oracle's restatement of
 the reference chunking (ppgs/model/transformer.py:49-64).  No compute calls."""
 import ctypes
+import math
 import os
 import re
 
@@ -88,6 +89,41 @@ def test_planner_random_lengths_property():
         got = [(w.item, w.start, w.frames, w.valid, w.keep_lo, w.keep_hi)
                for w in windows]
         assert got == reference_plan(T, lengths)
+
+
+@pytest.mark.parametrize('T,lengths,heads', [
+    (1000, [1000] * 32, 2),                                   # C2: 64 long windows + 32 short ones
+    (700, [700, 40, 300, 513, 700, 99, 17, 655], 2),          # ragged, exhausted windows
+    (160, [160, 3, 77, 160, 64, 65], 2),                      # every window fits a narrow tile or two
+    (1201, [1201, 800, 799, 401, 400, 0], 1),
+])
+def test_attention_items_cover_every_query_once_longest_first_xcd_affine(T, lengths, heads):
+    """The attention launch order (host planner): every query row of every computed window is in
+    exactly one tile; half-width tiles exactly for windows with <= half the longest window's keys
+    or <= 64 rows; longest first inside each of the 8 / gcd(8, heads) interleaved lanes; all tiles
+    of a window in ONE lane (they share an XCD's L2 for a given head)."""
+    windows, _ = E.plan_windows(len(lengths), T, lengths)
+    computed = [w for w in windows if w.tok_off >= 0]
+    items = E.plan_attention_items(len(lengths), T, lengths, heads=heads)
+    covered = {i: np.zeros(w.frames, dtype=int) for i, w in enumerate(computed)}
+    longest = max(w.valid for w in computed)
+    for it in items:
+        w = computed[it.window]
+        assert (it.frames, it.valid) == (w.frames, w.valid)
+        assert it.narrow == int(2 * w.valid <= longest or w.frames <= 64)
+        assert it.queries == (64 if it.narrow else 128) and it.q0 % it.queries == 0
+        covered[it.window][it.q0:it.q0 + it.queries] += 1
+    assert all((c == 1).all() for c in covered.values())
+    lanes = 8 // math.gcd(8, heads)
+    lane_of = {}
+    for position, it in enumerate(items):
+        lane_of.setdefault(it.window, set()).add(position % lanes)
+    full = len(items) - len(items) % lanes           # (the interleave runs ragged once a lane is exhausted)
+    multi = [w for w, ls in lane_of.items() if len(ls) > 1]
+    assert all(any(p >= full - lanes * 8 for p, it in enumerate(items) if it.window == w) for w in multi)
+    for lane in range(lanes):
+        valids = [it.valid for p, it in enumerate(items) if p % lanes == lane and p < full // 2]
+        assert valids == sorted(valids, reverse=True)
 
 
 def test_planner_legacy_mode_and_errors():
