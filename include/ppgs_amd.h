@@ -232,6 +232,30 @@ int ppg_resample(int device, const float* audio, int batch, int64_t samples,
                  int orig_rate, int new_rate, float* out, void* stream);
 
 /*
+ * Streaming causal mode.  The reference has no streaming
+ * state (ppgs/config/causal_transformer.py:18 only switches the causal mask on;
+ * every call is an independent forward), so the contract is defined here: a
+ * stream reproduces the causal forward of ONE utterance of up to `max_frames`
+ * (<= the chunk length: one window) frames, emitted incrementally while the
+ * K / V^T rows and the residual rows of everything seen stay on the device.
+ * Both 5-tap convolutions look 2 frames ahead, so after F frames the posteriors
+ * of frames < F - 4 are final; `flush` (end of utterance) finalises the rest.
+ * ppg_stream_push copies `n` new frames ((input_channels, n), device, the dtype
+ * given at creation) and computes what became final; the posteriors live in
+ * the stream's own buffer ppg_stream_posteriors(): (output_channels, rows)
+ * fp32, `rows` from ppg_stream_rows, column t = frame t; columns
+ * [*first_final, *first_final + *num_final) are the newly final ones.
+ * The engine must have been created with is_causal = 1.
+ */
+typedef struct PpgStream PpgStream;
+int ppg_stream_create(PpgEngine* engine, int max_frames, int feature_dtype, PpgStream** stream);
+void ppg_stream_destroy(PpgStream* stream);
+int ppg_stream_rows(const PpgStream* stream, int* rows, int* received_frames, int* final_frames);
+const float* ppg_stream_posteriors(const PpgStream* stream);
+int ppg_stream_push(PpgStream* stream, const void* chunk_device, int n_frames, int flush, int softmax,
+                    int* first_final, int* num_final, void* hip_stream);
+
+/*
  * wav2vec 2.0 feature encoder of the 'w2v2fb' representation (reference
  * ppgs/preprocess/w2v2fb/core.py:66 calls HF transformers
  * Wav2Vec2Model.feature_extractor -- Wav2Vec2FeatureEncoder of

@@ -1272,6 +1272,256 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
 }
 
 // ----------------------------------------------------------------------------
+// Streaming causal mode: one utterance, frames arrive in
+// chunks, the K / V^T rows and the residual rows of everything seen so far stay
+// on the device.  The reference defines no streaming state
+// (config/causal_transformer.py:18 only adds the causal mask): what this
+// reproduces is the causal forward of the WHOLE utterance (one window, <= the
+// chunk length), emitted incrementally.  With a causal mask, row t of every layer
+// depends on rows <= t of the layer below -- except for the two k = 5 'same'
+// convolutions (+-2 frames each).  After F frames:
+//   rows < F - 2 of the residual stream and of every layer are final,
+//   posteriors of rows < F - 4 are final (all of them after `flush`).
+// A step recomputes from the last 16-row block boundary at or below the previous
+// frontier (the kernels work on whole 16-row blocks; recomputing a row gives the
+// same bits), on ROW RANGES of the token-split kernels: pointers advanced by
+// row0, the window table's tok_off lowered by row0 so that window positions
+// (PE, masks, V^T columns) stay absolute.
+// ----------------------------------------------------------------------------
+struct PpgStream {
+    PpgEngine* e = nullptr;
+    int cap = 0, rows = 0, dtype = 0;
+    Workspace ws{};
+    char* buf = nullptr;          // workspace
+    char* feats = nullptr;        // (C, rows) in `dtype`
+    float* probs = nullptr;       // (output_channels, rows)
+    int* d_blk = nullptr;
+    PpgWindow* d_win = nullptr;   // [0] gather / linear launches, [1] out-conv
+    AttnItem* d_items = nullptr;
+    size_t qk_bytes = 0, vt_bytes = 0, cache_off = 0;
+    int received = 0, x_valid = 0, o_valid = 0;
+    bool finished = false;
+    // the per-step tables go up from pinned slots (a step's uploads are asynchronous: the source must outlive the call)
+    static constexpr int kSlots = 8, kMaxItems = 16;
+    struct Staging { PpgWindow win[3]; AttnItem items[kMaxItems]; };
+    Staging* staging = nullptr;
+    hipEvent_t uploaded[kSlots] = {};
+    unsigned step = 0;
+    ~PpgStream() {
+        if (e) (void)hipSetDevice(e->device);
+        for (void* p : {(void*)buf, (void*)feats, (void*)probs, (void*)d_blk, (void*)d_win, (void*)d_items}) if (p) (void)hipFree(p);
+        if (staging) (void)hipHostFree(staging);
+        for (hipEvent_t ev : uploaded) if (ev) (void)hipEventDestroy(ev);
+    }
+};
+
+int ppg_stream_create(PpgEngine* e, int max_frames, int feature_dtype, PpgStream** out) {
+    if (!e || !out) return fail(PPG_EINVAL, "null argument");
+    if (!e->cfg.is_causal) return fail(PPG_EINVAL, "streaming needs a causal engine (is_causal = 1)");
+    if (max_frames < 1 || max_frames > e->cfg.chunk_length)
+        return fail(PPG_ELENGTH, "max_frames %d outside [1, %d] (one window)", max_frames, e->cfg.chunk_length);
+    if (feature_dtype != PPG_DTYPE_F16 && feature_dtype != PPG_DTYPE_F32) return fail(PPG_EINVAL, "feature dtype %d", feature_dtype);
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_OK(hipSetDevice(e->device));
+    std::unique_ptr<PpgStream> st(new PpgStream);
+    st->e = e; st->cap = max_frames; st->rows = round_up(max_frames, 32); st->dtype = feature_dtype;
+    const PpgConfig& c = e->cfg;
+    st->ws = layout(e, st->rows, st->rows);
+    // hidden splits are chosen per step from the rows of the step: room for the most there can be
+    const int chunks = c.ffn_channels / (32768 / (c.hidden_channels * e->sz));
+    const size_t part_bytes = (size_t)std::max(1, chunks / 2) * st->rows * c.hidden_channels * 4;
+    // K | Q rows and V^T per LAYER (the one-shot forward reuses one pair for all layers; here they are the cache)
+    st->qk_bytes = align_up((size_t)st->ws.qk_rows * 2 * c.hidden_channels * e->sz, 256);
+    st->vt_bytes = align_up((size_t)c.hidden_channels * st->ws.vt_ld * e->sz, 256);
+    st->cache_off = align_up(st->ws.total + part_bytes, 256);
+    const size_t bytes = st->cache_off + (size_t)c.num_layers * (st->qk_bytes + st->vt_bytes);
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->buf), bytes));
+    HIP_OK(hipMemset(st->buf, 0, bytes));
+    const size_t esz = feature_dtype == PPG_DTYPE_F16 ? 2 : 4;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->feats), (size_t)c.input_channels * st->rows * esz));
+    HIP_OK(hipMemset(st->feats, 0, (size_t)c.input_channels * st->rows * esz));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->probs), (size_t)c.output_channels * st->rows * 4));
+    HIP_OK(hipMemset(st->probs, 0, (size_t)c.output_channels * st->rows * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_blk), (st->rows / 16 + 8) * sizeof(int)));
+    HIP_OK(hipMemset(st->d_blk, 0, (st->rows / 16 + 8) * sizeof(int)));          // every block belongs to window 0
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_win), 3 * sizeof(PpgWindow)));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_items), PpgStream::kMaxItems * sizeof(AttnItem)));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&st->staging), PpgStream::kSlots * sizeof(PpgStream::Staging), hipHostMallocDefault));
+    for (hipEvent_t& ev : st->uploaded) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_OK(hipDeviceSynchronize());
+    *out = st.release();
+    return PPG_OK;
+}
+
+void ppg_stream_destroy(PpgStream* stream) { delete stream; }
+
+int ppg_stream_rows(const PpgStream* st, int* rows, int* received, int* final_frames) {
+    if (!st) return fail(PPG_EINVAL, "null argument");
+    if (rows) *rows = st->rows;
+    if (received) *received = st->received;
+    if (final_frames) *final_frames = st->o_valid;
+    return PPG_OK;
+}
+
+const float* ppg_stream_posteriors(const PpgStream* st) { return st ? st->probs : nullptr; }
+
+int ppg_stream_push(PpgStream* st, const void* chunk, int n, int flush, int softmax,
+                    int* first_final, int* num_final, void* stream_) {
+    if (!st || (n > 0 && !chunk) || n < 0) return fail(PPG_EINVAL, "bad argument");
+    if (st->finished) return fail(PPG_EINVAL, "the stream was flushed");
+    if (st->received + n > st->cap) return fail(PPG_ELENGTH, "%d + %d frames > max_frames %d", st->received, n, st->cap);
+    PpgEngine* e = st->e;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_OK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const PpgConfig& c = e->cfg;
+    const int H = c.hidden_channels, F = c.ffn_channels, prec = c.precision, R = st->rows;
+    const size_t esz = st->dtype == PPG_DTYPE_F16 ? 2 : 4;
+
+    const int f_prev = st->received;
+    if (n > 0)
+        HIP_OK(hipMemcpy2DAsync(st->feats + (size_t)f_prev * esz, (size_t)R * esz, chunk, (size_t)n * esz,
+                                (size_t)n * esz, c.input_channels, hipMemcpyDeviceToDevice, s));
+    st->received += n;
+    const int x_prev = st->x_valid, o_prev = st->o_valid;
+    const int x_valid = flush ? st->received : std::max(st->received - 2, 0);
+    const int o_valid = flush ? st->received : std::max(x_valid - 2, 0);
+    if (first_final) *first_final = o_prev;
+    if (num_final) *num_final = o_valid - o_prev;
+    if (flush) st->finished = true;
+    const int r0 = x_prev / 16 * 16, r1 = round_up(x_valid, 16);          // rows of the residual stream to (re)compute
+    const int g0 = f_prev / 16 * 16, g1 = round_up(st->received, 16);      // rows whose features changed
+    const int o0 = o_prev / 16 * 16, o1 = round_up(o_valid, 16);          // posterior rows
+    st->x_valid = x_valid; st->o_valid = o_valid;
+
+#define LAUNCH_OK(expr, what)                                                        \
+    do {                                                                             \
+        hipError_t he_ = (expr);                                                     \
+        if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
+    } while (0)
+
+    char* base = st->buf;
+    const Workspace& ws = st->ws;
+    char* xw = base + ws.xw;
+    float* X = reinterpret_cast<float*>(base + ws.x);
+    char* Xb = e->sz == 2 ? base + ws.xb : nullptr;
+    char* ao = base + ws.ao;
+    float* part = reinterpret_cast<float*>(base + ws.total);
+    auto qk_of = [&](int l) { return base + st->cache_off + (size_t)l * (st->qk_bytes + st->vt_bytes); };
+    auto vt_of = [&](int l) { return qk_of(l) + st->qk_bytes; };
+    const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
+    const size_t xrow = (size_t)H * e->sz;
+
+    // the window as the launches of a row range [row0, ..) see it
+    PpgWindow w{};
+    w.item = 0; w.chunked = 0; w.start = 0; w.frames = R; w.valid = x_valid;
+    w.keep_lo = 0; w.keep_hi = R; w.out_frame = 0; w.vt_off = 0;
+    const unsigned slot_index = st->step++ % PpgStream::kSlots;
+    PpgStream::Staging& stage = st->staging[slot_index];
+    HIP_OK(hipEventSynchronize(st->uploaded[slot_index]));               // (its last use, kSlots steps ago, is long done)
+    auto upload_window = [&](int slot, int row0, int frames_seen) -> int {
+        PpgWindow& v = stage.win[slot];
+        v = w;
+        v.tok_off = -row0;
+        v.frames = frames_seen;
+        HIP_OK(hipMemcpyAsync(st->d_win + slot, &v, sizeof(v), hipMemcpyHostToDevice, s));
+        return PPG_OK;
+    };
+    int rc;
+    if (g1 > g0) {
+        if ((rc = upload_window(2, g0, R))) return rc;
+        GatherArgs g{};
+        g.feats = st->feats; g.dtype = st->dtype; g.C = c.input_channels; g.T = R; g.overlap = c.chunk_overlap;
+        g.xw = xw + (size_t)g0 * e->Cp * e->sz; g.Cp = e->Cp;
+        g.blk_win = st->d_blk; g.win = st->d_win + 2; g.M = g1 - g0;
+        g.vt = vt_of(0); g.vt_ld = ws.vt_ld; g.vt_rows = H; g.vt_tokens = R; g.nwin = 0;     // (no window tails to clear: R is a multiple of 32; the caches were zeroed at creation)
+        g.qk_slack = qk_of(0) + (size_t)R * 2 * H * e->sz; g.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
+        LAUNCH_OK(ppg::launch_gather(prec, g, s), "stream gather");
+    }
+    if (r1 > r0) {
+        const int M = r1 - r0;
+        if ((rc = upload_window(0, r0, R))) return rc;
+        const int lnt = 1;
+        auto base_args = [&]() {
+            LinearArgs a{};
+            a.blk_win = st->d_blk; a.win = st->d_win; a.M = M; a.H = H;
+            a.X = X + (size_t)r0 * H; a.Xb = Xb ? Xb + (size_t)r0 * H * 2 : nullptr; a.v_start = INT_MAX; a.taps = 1;
+            return a;
+        };
+        {
+            LinearArgs a = base_args();
+            a.act = xw + (size_t)r0 * e->Cp * e->sz; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
+            a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
+            a.total_groups = e->in_total_groups;
+            a.W = e->w_in; a.bias = e->b_in; a.N = H; a.pe = e->pe;
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, lnt, a, H / 256, s), "stream in-conv");
+        }
+        // attention items: query tiles that cover [r0, r1)
+        const int qt = ppg::attn_query_tile(e->head_dim), tile = e->head_dim == 128 ? qt / 2 : qt;
+        int nitems = 0;
+        for (int q0 = r0 / tile * tile; q0 < r1; q0 += tile) {
+            if (nitems == PpgStream::kMaxItems) return fail(PPG_EINVAL, "a step of %d rows needs more than %d query tiles", M, PpgStream::kMaxItems);
+            stage.items[nitems++] = AttnItem{0, q0, 0, 0, R, x_valid, e->head_dim == 128 ? 1 : 0, 0};
+        }
+        HIP_OK(hipMemcpyAsync(st->d_items, stage.items, nitems * sizeof(AttnItem), hipMemcpyHostToDevice, s));
+        int nt = 1, splits = 1;
+        choose_ffn_tiling(e, M, &nt, &splits);
+        if (nt == ppg::kFfnMixedTiling) nt = 1;
+        const int hg = H / e->KG;
+        for (int l = 0; l < c.num_layers; ++l) {
+            const DevLayer& d = e->layers[l];
+            char* qk = qk_of(l);
+            char* vt = vt_of(l);
+            {
+                LinearArgs a = base_args();
+                a.act = act_x + (size_t)r0 * xrow; a.lda_bytes = H * e->sz;
+                a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
+                a.W = d.wqkv; a.bias = d.bqkv; a.N = 3 * H;
+                a.out_rows = qk + (size_t)r0 * 2 * H * e->sz; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, lnt, a, 3 * H / 256, s), "stream qkv");
+            }
+            {
+                AttnArgs a{};
+                a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
+                a.ao = ao; a.H = H; a.causal = 1;
+                a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
+                a.items = st->d_items; a.win = st->d_win; a.M = R; a.ao_tiled = 0; a.heads = c.heads;
+                LAUNCH_OK(ppg::launch_attn(prec, a, nitems, c.heads, e->head_dim, s), "stream attention");
+            }
+            {
+                LinearArgs a = base_args();
+                a.act = ao + (size_t)r0 * xrow; a.lda_bytes = H * e->sz;
+                a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
+                a.W = d.wo; a.bias = d.bo; a.N = H; a.gamma = d.g1; a.beta = d.e1;
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, 1, a, 1, s), "stream out-proj+LN");
+            }
+            {
+                FfnArgs a{};
+                a.X = X + (size_t)r0 * H; a.Xb = Xb ? Xb + (size_t)r0 * H * 2 : nullptr;
+                a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M;
+                a.splits = splits; a.partial = splits > 1 ? part : nullptr;
+                LAUNCH_OK(ppg::launch_ffn(prec, a, nt, s), "stream ffn");
+            }
+        }
+    }
+    if (o1 > o0) {
+        if ((rc = upload_window(1, o0, flush ? st->received : R))) return rc;
+        LinearArgs a{};
+        a.blk_win = st->d_blk; a.win = st->d_win + 1; a.M = o1 - o0; a.H = H; a.v_start = INT_MAX;
+        a.act = act_x + (size_t)o0 * xrow; a.lda_bytes = H * e->sz; a.taps = 5;
+        a.groups_per_tap = e->out_groups_per_tap; a.real_groups = 5 * e->out_groups_per_tap;
+        a.total_groups = e->out_total_groups;
+        a.W = e->w_out; a.bias = e->b_out; a.N = 48;
+        a.out = st->probs; a.out_T = R; a.out_C = c.output_channels; a.softmax = softmax;
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, 1, a, 1, s), "stream out-conv+softmax");
+    }
+#undef LAUNCH_OK
+    HIP_OK(hipEventRecord(st->uploaded[slot_index], s));
+    return PPG_OK;
+}
+
+// ----------------------------------------------------------------------------
 // wav2vec 2.0 feature encoder (w2v2fb representation)
 // ----------------------------------------------------------------------------
 namespace {

@@ -105,6 +105,16 @@ SYMBOLS = {
     'ppg_grid_sample': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_stream_create': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'ppg_stream_destroy': (None, [ctypes.c_void_p]),
+    'ppg_stream_rows': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+        ctypes.POINTER(ctypes.c_int)]),
+    'ppg_stream_posteriors': (ctypes.c_void_p, [ctypes.c_void_p]),
+    'ppg_stream_push': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     'ppg_w2v2_create': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'ppg_w2v2_destroy': (None, [ctypes.c_void_p]),
@@ -282,6 +292,11 @@ class Engine:
             self._handle, batch, frames, _lengths_array(lengths, batch),
             int(legacy_mode), ctypes.byref(size)))
         return size.value
+
+    def stream(self, max_frames, dtype=torch.float16):
+        """A KV-cached causal stream over one utterance of up to `max_frames` frames
+        (see Stream); the engine must be causal."""
+        return Stream(self, max_frames, dtype)
 
     def encode(self, features, lengths, softmax=True, legacy_mode=False,
                workspace=None):
@@ -504,6 +519,85 @@ def grid_sample(ppg, grid):
 
 class PpgW2v2Weights(ctypes.Structure):
     _fields_ = [('conv_weight', _FP * 7), ('norm_weight', _FP), ('norm_bias', _FP)]
+
+
+class Stream:
+    """Streaming causal inference over ONE utterance (include/ppgs_amd.h: ppg_stream_*).
+
+    The reference has no streaming mode: its causal configuration runs every chunk as an
+    independent forward (ppgs/config/causal_transformer.py:18).  A Stream produces what the
+    causal forward of the whole utterance (one window, <= 500 frames) produces, a chunk at
+    a time, keeping K / V^T and the residual rows of everything seen on the device.  Both
+    5-tap convolutions look two frames ahead, so push() returns the posteriors that became
+    final: frames < received - 4 (all of them after flush=True)."""
+
+    def __init__(self, engine, max_frames, dtype=torch.float16):
+        if dtype not in (torch.float16, torch.float32):
+            raise ValueError('stream features are fp16 or fp32')
+        self.engine = engine
+        self.dtype = dtype
+        self._lib = engine._lib
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(engine.device):
+            _check(self._lib.ppg_stream_create(
+                engine._handle, int(max_frames), 0 if dtype == torch.float16 else 1,
+                ctypes.byref(handle)))
+        self._handle = handle
+        rows = ctypes.c_int()
+        _check(self._lib.ppg_stream_rows(self._handle, ctypes.byref(rows), None, None))
+        self.rows = rows.value
+        self.max_frames = int(max_frames)
+
+    def __del__(self):
+        handle, self._handle = getattr(self, '_handle', None), None
+        if handle:
+            self._lib.ppg_stream_destroy(handle)
+
+    @property
+    def received(self):
+        value = ctypes.c_int()
+        _check(self._lib.ppg_stream_rows(self._handle, None, ctypes.byref(value), None))
+        return value.value
+
+    def push(self, chunk, flush=False, softmax=True):
+        """chunk (input_channels, n) on the engine's GPU (n may be 0 with flush=True) ->
+        (40, k) fp32: the posteriors (logits if softmax=False) of the k frames that became
+        final with this chunk, in order."""
+        engine = self.engine
+        if chunk is None:
+            chunk = torch.empty(engine.input_channels, 0, dtype=self.dtype, device=engine.device)
+        if chunk.dim() != 2 or chunk.shape[0] != engine.input_channels:
+            raise ValueError(f'chunk must be ({engine.input_channels}, frames), got {tuple(chunk.shape)}')
+        chunk = chunk.to(device=engine.device, dtype=self.dtype).contiguous()
+        first, count = ctypes.c_int(), ctypes.c_int()
+        with torch.cuda.device(engine.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(self._lib.ppg_stream_push(
+                self._handle, ctypes.c_void_p(chunk.data_ptr()), chunk.shape[1], int(flush),
+                int(softmax), ctypes.byref(first), ctypes.byref(count),
+                ctypes.c_void_p(stream)))
+            out = torch.empty(engine.output_channels, count.value, dtype=torch.float32,
+                              device=engine.device)
+            if count.value:
+                # the stream owns (output_channels, rows) fp32; copy the newly final columns out
+                # (ordered behind the step on the current stream)
+                address = self._lib.ppg_stream_posteriors(self._handle)
+                source = _device_view(address, (engine.output_channels, self.rows), engine.device)
+                out.copy_(source[:, first.value:first.value + count.value])
+        return out
+
+
+def _device_view(address, shape, device):
+    """fp32 tensor view of device memory the library owns (no copy)."""
+    import numpy as np
+
+    class _Holder:
+        pass
+    holder = _Holder()
+    count = int(np.prod(shape))
+    holder.__cuda_array_interface__ = {
+        'shape': (count,), 'typestr': '<f4', 'data': (int(address), False), 'version': 2}
+    return torch.as_tensor(holder, device=device).view(*shape)
 
 
 class W2v2FeatureEncoder:

@@ -668,6 +668,45 @@ def test_c5_causal_streaming_chunks_and_graph_replay():
     assert (again - static_out).abs().max() == 0
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'fp16', 'bf16'])
+def test_kv_cached_stream_equals_causal_forward(precision):
+    """Streaming causal mode (ppg_stream_*): an utterance pushed in ragged chunks (1 .. 100
+    frames, not multiples of the kernels' 16-row blocks) with the K / V^T and residual rows
+    cached on the device yields, frame by frame, the causal forward of the whole utterance --
+    oracle (reference Transformer.forward with is_causal, one window) and the engine's own
+    one-shot encode.  Only frames < received - 4 may be emitted before the flush (two 5-tap
+    convolutions look two frames ahead each)."""
+    engine, state = eng(precision=precision, causal=True)
+    gen = torch.Generator().manual_seed(41)
+    total = 437
+    feats = torch.randn(80, total, generator=gen).half()
+    ref = O.from_features(state, feats[None].float(), torch.tensor([total]), is_causal=True).numpy()[0]
+    one_shot = run(engine, feats[None], [total])[0]
+    stream = engine.stream(500)
+    assert stream.rows == 512
+    pieces, received = [], 0
+    for n in (16, 48, 7, 100, 1, 64, 33, 90, 2, 76):
+        out = stream.push(feats[:, received:received + n].cuda())
+        received += n
+        pieces.append(out)
+        assert sum(p.shape[1] for p in pieces) == max(received - 4, 0)
+    assert received == total and stream.received == total
+    pieces.append(stream.push(None, flush=True))
+    torch.cuda.synchronize()
+    streamed = torch.cat(pieces, dim=1).cpu().numpy()
+    assert streamed.shape == (40, total) and np.isfinite(streamed).all()
+    assert np.abs(streamed - ref).max() < TOL[precision]
+    # same kernels on the same rows as the one-shot forward (token-split path at this size): the 16-bit modes
+    # agree with it much closer than with the fp32 oracle
+    assert np.abs(streamed - one_shot).max() < (FP32_TOL if precision == 'fp32' else 2e-3)
+    with pytest.raises(ValueError):
+        stream.push(feats[:, :1].cuda())               # flushed
+    with pytest.raises(ValueError):
+        eng(precision=precision)[0].stream(100)        # not a causal engine
+    with pytest.raises((ValueError, E.PpgError)):
+        engine.stream(501)                             # more than one window
+
+
 def test_large_ragged_batch_and_legacy_mode():
     """Many windows (B=96 x T=2600 -> 7 windows per item, ~270k token rows),
     and legacy (unchunked) mode on a 1200-frame item: finite, normalised, and

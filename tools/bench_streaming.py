@@ -55,6 +55,27 @@ def main():
     torch.cuda.synchronize()
     kernels = {n: v[0] / 5 for n, v in model.profile_read().items()}
     launches = {n: v[1] / 5 for n, v in model.profile_read().items()}
+    # KV-cached stream of ONE utterance (ppg_stream_*): latency of a push in steady state (frames 200 .. 480 of a
+    # 500-frame window), the whole step synchronised (what a caller that consumes the posteriors sees)
+    def stream_latency(n):
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(3):
+            stream = model.stream(500)
+            chunk = torch.randn(80, n, generator=generator).half().cuda()
+            received = 0
+            while received + n <= 480:
+                torch.cuda.synchronize()
+                start = time.perf_counter()
+                stream.push(chunk)
+                torch.cuda.synchronize()
+                if received >= 200:
+                    times.append(time.perf_counter() - start)
+                received += n
+        times.sort()
+        return {'frames_per_push': n, 'median_us': times[len(times) // 2] * 1e6, 'p90_us': times[int(len(times) * 0.9)] * 1e6,
+                'pushes_timed': len(times)}
+    kv = [stream_latency(n) for n in (16, 48, 160)]
     per_step = args.batch * args.frames
     # single 160-frame windows: 13 414 400 FLOP per frame + 5120 Tc^2 per window (causal
     # attention computes about half of the Tc^2 term)
@@ -70,6 +91,8 @@ def main():
         'hipgraph_replay': {'us_per_step': graphed * 1e6, 'steps_per_s': 1 / graphed, 'frames_per_s': per_step / graphed},
         'end_to_end_tflops': flops / graphed / 1e12,
         'kernel_ms_per_step': kernels,
+        'kv_cached_stream': {'what': 'one utterance, K / V^T and residual rows of all layers cached on the device, 14 + 4 x 5 '
+                                     'launches per push on row ranges of the token-split kernels; wall time of push() + synchronize', 'steps': kv},
         'roofline': {'kernel': 'layer kernel launches (10 240 token rows: token-split, hidden chunks split over workgroups)',
                      'bound': 'mfma', 'achieved': layer_flops / layer_ms / 1e9, 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': layer_flops / layer_ms / 1e9 / peak, 'mean_launch_ms': layer_ms},
