@@ -232,6 +232,57 @@ int ppg_resample(int device, const float* audio, int batch, int64_t samples,
                  int orig_rate, int new_rate, float* out, void* stream);
 
 /*
+ * wav2vec 2.0 transformer body on the HIP engine: what HF
+ * `Wav2Vec2Model.forward` runs after the convolutional feature encoder --
+ * feature_projection (LayerNorm 512 + Linear 512 -> hidden), the encoder's
+ * grouped positional convolution (k = 128, 16 groups, GELU) + residual +
+ * LayerNorm, and `num_layers` post-norm layers (self-attention with a key
+ * padding mask, FFN with exact GELU) -- transformers/models/wav2vec2/
+ * modeling_wav2vec2.py: Wav2Vec2FeatureProjection, Wav2Vec2PositionalConvEmbedding,
+ * Wav2Vec2Encoder (do_stable_layer_norm = False), Wav2Vec2EncoderLayer.
+ * Weights are host fp32 in torch layouts; `pos_conv_weight` is the EFFECTIVE
+ * convolution weight (weight norm applied): (hidden, hidden / groups, kernel).
+ *   features     : device fp32 (batch, frames, 512) = ppg_w2v2_features' output
+ *   valid_frames : HOST int64[batch]: frames of each item that are real (HF's
+ *                  frame-level attention mask); rows past it are zeroed after
+ *                  the projection and masked as attention keys
+ *   out          : device fp32 (batch, frames, hidden) = last_hidden_state
+ */
+#define PPG_W2V2_MAX_LAYERS 24
+typedef struct PpgW2v2LayerWeights {
+    const float* q_weight; const float* q_bias;            /* (hidden, hidden), (hidden)  */
+    const float* k_weight; const float* k_bias;
+    const float* v_weight; const float* v_bias;
+    const float* out_weight; const float* out_bias;
+    const float* norm1_weight; const float* norm1_bias;    /* layer_norm                  */
+    const float* ffn1_weight; const float* ffn1_bias;      /* intermediate_dense (ffn, hidden) */
+    const float* ffn2_weight; const float* ffn2_bias;      /* output_dense (hidden, ffn)  */
+    const float* norm2_weight; const float* norm2_bias;    /* final_layer_norm            */
+} PpgW2v2LayerWeights;
+typedef struct PpgW2v2BodyWeights {
+    int32_t hidden;          /* 768  */
+    int32_t heads;           /* 12 (hidden / heads = 64) */
+    int32_t ffn;             /* 3072 */
+    int32_t num_layers;
+    int32_t conv_kernel;     /* 128  */
+    int32_t conv_groups;     /* 16   */
+    float layer_norm_eps;    /* 1e-5 */
+    int32_t pad0;
+    const float* proj_norm_weight; const float* proj_norm_bias;   /* (512)                */
+    const float* proj_weight; const float* proj_bias;             /* (hidden, 512)        */
+    const float* pos_conv_weight; const float* pos_conv_bias;     /* see above            */
+    const float* enc_norm_weight; const float* enc_norm_bias;     /* (hidden)             */
+    PpgW2v2LayerWeights layers[PPG_W2V2_MAX_LAYERS];
+} PpgW2v2BodyWeights;
+typedef struct PpgW2v2Body PpgW2v2Body;
+int ppg_w2v2_body_create(const PpgW2v2BodyWeights* weights, int precision, int device, PpgW2v2Body** out);
+void ppg_w2v2_body_destroy(PpgW2v2Body* body);
+int ppg_w2v2_body_workspace_bytes(const PpgW2v2Body* body, int batch, int frames, size_t* bytes);
+int ppg_w2v2_body_forward(PpgW2v2Body* body, const float* features, const int64_t* valid_frames_host,
+                          int batch, int frames, float* out, void* workspace, size_t workspace_bytes,
+                          void* hip_stream);
+
+/*
  * Streaming causal mode.  The reference has no streaming
  * state (ppgs/config/causal_transformer.py:18 only switches the causal mask on;
  * every call is an independent forward), so the contract is defined here: a

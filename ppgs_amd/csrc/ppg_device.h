@@ -223,6 +223,8 @@ enum {
     EPI_RELU = 3,     // +bias, ReLU -> hidden (unfused FFN path)
     EPI_OUTCONV = 4,  // +bias, mask, softmax over 40, scatter into (B,40,T)
     EPI_GELU = 5,     // strided k-tap conv without bias + exact GELU -> out_rows (wav2vec2 feature encoder layers 1..6)
+    EPI_GENERAL = 6,  // +bias, [exact GELU / ReLU], [zero rows past the window's valid], [+fp32 residual] -> fp32 and / or 16-bit rows
+                      // (wav2vec2 transformer body: projections, grouped positional conv as taps x groups over blockIdx.y)
 };
 
 struct LinearArgs {
@@ -258,6 +260,13 @@ struct LinearArgs {
     int x_tiled;              // EPI_INCONV: X is written in X32 order (the layer32 kernel follows)
     int stride;               // EPI_GELU: output row m reads input rows stride * m + tap, tap = 0 .. taps - 1
     int M_in;                 // EPI_GELU: rows of the input buffer
+    // EPI_GENERAL
+    int act_fn;               // 0 none, 1 ReLU, 2 exact GELU
+    int zero_invalid;         // rows at or past their window's valid length come out as zeros
+    const float* residual;    // fp32 [M][out_ld32] added after the activation, or null
+    float* out32;             // fp32 [M][out_ld32], or null
+    int out_ld32;
+    int act_y_stride;         // bytes added to `act` per blockIdx.y (grouped convolution: group y reads its own channels)
 };
 
 struct FfnArgs {

@@ -1657,6 +1657,275 @@ int ppg_w2v2_features(PpgW2v2* model, const float* audio, int batch, int64_t sam
     return PPG_OK;
 }
 
+// ----------------------------------------------------------------------------
+// wav2vec 2.0 transformer body (include/ppgs_amd.h: ppg_w2v2_body_*).  A first, unfused form on the engine's
+// generic kernels: every projection is linear_kernel<EPI_GENERAL> (bias, GELU, residual in the epilogue), the
+// LayerNorms (width 768 does not fit the GEMM epilogues' register tiles) are w2v2_layernorm_kernel, attention is
+// attn_kernel<.., 1, 64>, the positional convolution is 16 grouped GEMMs of one launch (blockIdx.y = group: taps 128,
+// 48 channels of a group = 1.5 K-groups of 64 bytes in the 16-bit modes, read as 2 with zero weights for the 16
+// channels of the neighbouring group).  Token space: item b owns rows b R .. b R + frames - 1, R = frames rounded
+// up to 32 (no half-written V^T groups); one attention window per item, keys limited to its valid frames.
+// ----------------------------------------------------------------------------
+struct PpgW2v2Body {
+    PpgEngine eng;
+    int hidden = 0, heads = 0, ffn = 0, layers = 0, taps = 0, groups = 0, gpt = 0;
+    float eps = 1e-5f;
+    float* pn_g = nullptr; float* pn_b = nullptr;
+    char* proj_w = nullptr; float* proj_b = nullptr;
+    char* pos_w = nullptr; float* pos_b = nullptr;
+    float* en_g = nullptr; float* en_b = nullptr;
+    struct Layer { char* wqkv; float* bqkv; char* wo; float* bo; float* g1; float* e1; char* w1; float* b1; char* w2; float* b2; float* g2; float* e2; };
+    std::vector<Layer> layer;
+    char* staging = nullptr;       // pinned: window / block / item tables of the call in flight
+    size_t staging_bytes = 0;
+    hipEvent_t uploaded = nullptr;
+    ~PpgW2v2Body() {
+        (void)hipSetDevice(eng.device);
+        if (staging) (void)hipHostFree(staging);
+        if (uploaded) (void)hipEventDestroy(uploaded);
+    }
+};
+
+int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device, PpgW2v2Body** out) {
+    if (!w || !out) return fail(PPG_EINVAL, "null argument");
+    if (precision != PPG_PRECISION_FP32 && precision != PPG_PRECISION_BF16 && precision != PPG_PRECISION_FP16)
+        return fail(PPG_EINVAL, "precision %d", precision);
+    const int H = w->hidden, F = w->ffn, L = w->num_layers;
+    if (H != 768 || w->heads <= 0 || H / w->heads != 64 || H % w->heads) return fail(PPG_EINVAL, "hidden %d / heads %d: the body kernels are built for 768 = 12 x 64", H, w->heads);
+    if (F <= 0 || F % 256 || L < 0 || L > PPG_W2V2_MAX_LAYERS) return fail(PPG_EINVAL, "ffn %d, layers %d", F, L);
+    if (w->conv_groups != 16 || w->conv_kernel <= 0 || w->conv_kernel % 2 || H / w->conv_groups != 48)
+        return fail(PPG_EINVAL, "positional convolution: kernel %d groups %d", w->conv_kernel, w->conv_groups);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PPG_EDEVICE, "no HIP device: the wav2vec2 body has no CPU path");
+    if (device < 0 || device >= ndev) return fail(PPG_EDEVICE, "device %d of %d", device, ndev);
+    HIP_OK(hipSetDevice(device));
+    std::unique_ptr<PpgW2v2Body> m(new PpgW2v2Body());
+    PpgEngine* E = &m->eng;
+    E->device = device; E->cfg.precision = precision;
+    E->sz = precision == PPG_PRECISION_FP32 ? 4 : 2;
+    E->KG = 64 / E->sz;
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    E->num_cus = prop.multiProcessorCount;
+    m->hidden = H; m->heads = w->heads; m->ffn = F; m->layers = L; m->taps = w->conv_kernel; m->groups = w->conv_groups;
+    m->eps = w->layer_norm_eps;
+    const int CG = H / w->conv_groups;                       // 48 channels per group
+    m->gpt = (CG * E->sz + 63) / 64;                         // K-groups of 64 bytes per tap: 2 (16-bit, padded) or 3 (fp32)
+    int rc;
+#define NEED(ptr) if (!(ptr)) return fail(PPG_EINVAL, #ptr " is null")
+    NEED(w->proj_norm_weight); NEED(w->proj_norm_bias); NEED(w->proj_weight); NEED(w->proj_bias);
+    NEED(w->pos_conv_weight); NEED(w->pos_conv_bias); NEED(w->enc_norm_weight); NEED(w->enc_norm_bias);
+    auto paired = [&](const float* src, int rows, int cols, char** dst) {
+        return upload_matrix(E, rows, cols, rows, cols, [&](int r, int c) { return src[(size_t)pair_row(r) * cols + c]; }, dst);
+    };
+    if ((rc = upload_f32(E, w->proj_norm_weight, 512, 0, &m->pn_g))) return rc;
+    if ((rc = upload_f32(E, w->proj_norm_bias, 512, 0, &m->pn_b))) return rc;
+    if ((rc = paired(w->proj_weight, H, 512, &m->proj_w))) return rc;
+    if ((rc = upload_f32(E, w->proj_bias, H, 0, &m->proj_b))) return rc;
+    {   // W'[n][tap * gpt * KG + c] = w[n][c][tap] for c < 48 (n's own group), 0 for the pad channels; plain row order
+        const int taps = m->taps, kk = m->gpt * E->KG;
+        const float* pw = w->pos_conv_weight;
+        rc = upload_matrix(E, H, taps * kk, H, taps * kk,
+                           [&](int n, int col) { const int tap = col / kk, c = col - tap * kk; return c < CG ? pw[((size_t)n * CG + c) * taps + tap] : 0.f; },
+                           &m->pos_w);
+        if (rc) return rc;
+    }
+    if ((rc = upload_f32(E, w->pos_conv_bias, H, 0, &m->pos_b))) return rc;
+    if ((rc = upload_f32(E, w->enc_norm_weight, H, 0, &m->en_g))) return rc;
+    if ((rc = upload_f32(E, w->enc_norm_bias, H, 0, &m->en_b))) return rc;
+    m->layer.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const PpgW2v2LayerWeights& lw = w->layers[l];
+        PpgW2v2Body::Layer& d = m->layer[l];
+        NEED(lw.q_weight); NEED(lw.q_bias); NEED(lw.k_weight); NEED(lw.k_bias); NEED(lw.v_weight); NEED(lw.v_bias);
+        NEED(lw.out_weight); NEED(lw.out_bias); NEED(lw.norm1_weight); NEED(lw.norm1_bias);
+        NEED(lw.ffn1_weight); NEED(lw.ffn1_bias); NEED(lw.ffn2_weight); NEED(lw.ffn2_bias); NEED(lw.norm2_weight); NEED(lw.norm2_bias);
+        // in_proj = [q; k; v] rows, each block of 3H in paired order (linear_kernel<EPI_QKV>)
+        rc = upload_matrix(E, 3 * H, H, 3 * H, H,
+                           [&](int r, int c) {
+                               const int rr = pair_row(r), which = rr / H, row = rr - which * H;
+                               const float* src = which == 0 ? lw.q_weight : (which == 1 ? lw.k_weight : lw.v_weight);
+                               return src[(size_t)row * H + c];
+                           }, &d.wqkv);
+        if (rc) return rc;
+        std::vector<float> bq(3 * (size_t)H);
+        memcpy(bq.data(), lw.q_bias, H * sizeof(float));
+        memcpy(bq.data() + H, lw.k_bias, H * sizeof(float));
+        memcpy(bq.data() + 2 * H, lw.v_bias, H * sizeof(float));
+        if ((rc = upload_f32(E, bq.data(), 3 * (size_t)H, 0, &d.bqkv))) return rc;
+        if ((rc = paired(lw.out_weight, H, H, &d.wo))) return rc;
+        if ((rc = upload_f32(E, lw.out_bias, H, 0, &d.bo))) return rc;
+        if ((rc = upload_f32(E, lw.norm1_weight, H, 0, &d.g1))) return rc;
+        if ((rc = upload_f32(E, lw.norm1_bias, H, 0, &d.e1))) return rc;
+        if ((rc = paired(lw.ffn1_weight, F, H, &d.w1))) return rc;
+        if ((rc = upload_f32(E, lw.ffn1_bias, F, 0, &d.b1))) return rc;
+        if ((rc = paired(lw.ffn2_weight, H, F, &d.w2))) return rc;
+        if ((rc = upload_f32(E, lw.ffn2_bias, H, 0, &d.b2))) return rc;
+        if ((rc = upload_f32(E, lw.norm2_weight, H, 0, &d.g2))) return rc;
+        if ((rc = upload_f32(E, lw.norm2_bias, H, 0, &d.e2))) return rc;
+    }
+#undef NEED
+    HIP_OK(hipEventCreateWithFlags(&m->uploaded, hipEventDisableTiming));
+    *out = m.release();
+    return PPG_OK;
+}
+
+void ppg_w2v2_body_destroy(PpgW2v2Body* body) { delete body; }
+
+namespace {
+struct BodyLayout { size_t win, blk, items, ln, x, p, xb, qk, vt, ao, hid, total; int R, M, nitems; };
+BodyLayout body_layout(const PpgW2v2Body* m, int batch, int frames) {
+    BodyLayout L{};
+    const int H = m->hidden, sz = m->eng.sz;
+    L.R = round_up(frames, 32);
+    L.M = batch * L.R;
+    L.nitems = batch * ((frames + 63) / 64);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.win = take((size_t)batch * sizeof(PpgWindow));
+    L.blk = take((size_t)(L.M / 16) * sizeof(int));
+    L.items = take((size_t)L.nitems * sizeof(AttnItem));
+    L.ln = take(((size_t)L.M + 1) * 512 * sz);
+    L.x = take((size_t)L.M * H * 4);
+    L.p = take((size_t)L.M * H * 4);
+    L.xb = take(((size_t)L.M + 1) * H * sz + 256);            // (the last group's pad channels read 32 bytes past a row)
+    L.qk = take(((size_t)L.M + 64) * 2 * H * sz);
+    L.vt = take((size_t)H * (L.M + 64) * sz);
+    L.ao = take((size_t)L.M * H * sz);
+    L.hid = take((size_t)L.M * m->ffn * sz);
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+int ppg_w2v2_body_workspace_bytes(const PpgW2v2Body* body, int batch, int frames, size_t* bytes) {
+    if (!body || !bytes || batch <= 0 || frames <= 0) return fail(PPG_EINVAL, "bad argument");
+    *bytes = body_layout(body, batch, frames).total;
+    return PPG_OK;
+}
+
+int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* valid_frames, int batch, int frames,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !features || !valid_frames || !out || !workspace || batch <= 0 || frames <= 0) return fail(PPG_EINVAL, "bad argument");
+    for (int b = 0; b < batch; ++b)
+        if (valid_frames[b] < 1 || valid_frames[b] > frames) return fail(PPG_EINVAL, "valid_frames[%d]=%lld outside [1, %d]", b, (long long)valid_frames[b], frames);
+    const BodyLayout L = body_layout(m, batch, frames);
+    if (workspace_bytes < L.total) return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, L.total);
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(PPG_EINVAL, "workspace not 256-byte aligned");
+    PpgEngine* E = &m->eng;
+    HIP_OK(hipSetDevice(E->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int H = m->hidden, F = m->ffn, sz = E->sz, prec = E->cfg.precision, M = L.M, R = L.R;
+    char* base = static_cast<char*>(workspace);
+
+    // tables: one window per item, every 16-row block of item b -> window b, query tiles of 64
+    const size_t table_bytes = L.ln;                           // win | blk | items are the first three regions
+    if (m->staging_bytes < table_bytes) {
+        if (m->staging) { HIP_OK(hipEventSynchronize(m->uploaded)); (void)hipHostFree(m->staging); m->staging = nullptr; }
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&m->staging), table_bytes, hipHostMallocDefault));
+        m->staging_bytes = table_bytes;
+    }
+    HIP_OK(hipEventSynchronize(m->uploaded));                  // the previous call's upload has left the staging buffer
+    memset(m->staging, 0, table_bytes);
+    PpgWindow* hw = reinterpret_cast<PpgWindow*>(m->staging + L.win);
+    int* hb = reinterpret_cast<int*>(m->staging + L.blk);
+    AttnItem* hi = reinterpret_cast<AttnItem*>(m->staging + L.items);
+    int ni = 0;
+    for (int b = 0; b < batch; ++b) {
+        PpgWindow& w = hw[b];
+        w.item = b; w.frames = frames; w.valid = (int)valid_frames[b]; w.keep_lo = 0; w.keep_hi = frames;
+        w.tok_off = b * R; w.vt_off = b * R;
+        for (int k = 0; k < R / 16; ++k) hb[b * (R / 16) + k] = b;
+        for (int q0 = 0; q0 < frames; q0 += 64) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, 0, 0};
+    }
+    HIP_OK(hipMemsetAsync(base + L.ln, 0, L.hid - L.ln, s));    // padding rows, slack columns: finite (masked keys are still multiplied)
+    HIP_OK(hipMemcpyAsync(base, m->staging, table_bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipEventRecord(m->uploaded, s));
+    const PpgWindow* d_win = reinterpret_cast<const PpgWindow*>(base + L.win);
+    const int* d_blk = reinterpret_cast<const int*>(base + L.blk);
+    const AttnItem* d_items = reinterpret_cast<const AttnItem*>(base + L.items);
+    char* ln = base + L.ln;
+    float* X = reinterpret_cast<float*>(base + L.x);
+    float* P = reinterpret_cast<float*>(base + L.p);
+    char* Xb = base + L.xb;
+    char* qk = base + L.qk;
+    char* vt = base + L.vt;
+    char* ao = base + L.ao;
+    char* hid = base + L.hid;
+    const int vt_ld = M + 64;
+    // operand rows of the residual stream: the 16-bit copy, or X itself in fp32 mode
+    const char* act_x = sz == 2 ? Xb : reinterpret_cast<const char*>(X);
+    char* xb_out = sz == 2 ? Xb : nullptr;
+
+#define LAUNCH_OK(expr, what)                                                        \
+    do {                                                                             \
+        hipError_t he_ = (expr);                                                     \
+        if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
+    } while (0)
+    const int nt = std::min(choose_nt(E, M, 2), 2);
+    auto general = [&](const char* act, int k_elems, const char* W, const float* bias, int N) {
+        LinearArgs a{};
+        a.blk_win = d_blk; a.win = d_win; a.M = M; a.H = H; a.v_start = INT_MAX; a.taps = 1;
+        a.act = act; a.lda_bytes = k_elems * sz;
+        a.groups_per_tap = k_elems / E->KG; a.real_groups = a.total_groups = a.groups_per_tap;
+        a.W = W; a.bias = bias; a.N = N; a.out_ld32 = H;
+        return a;
+    };
+    auto layer_norm = [&](const float* g, const float* b) {
+        return ppg::launch_w2v2_layernorm(prec, H, P, nullptr, g, b, M, M, M, m->eps, X, xb_out, s);
+    };
+    // feature projection: LayerNorm(512) -> Linear, rows past the valid frames zeroed (HF: hidden_states[~mask] = 0)
+    LAUNCH_OK(ppg::launch_w2v2_layernorm(prec, 512, features, nullptr, m->pn_g, m->pn_b, (long)batch * frames, frames, R, m->eps,
+                                         sz == 2 ? nullptr : reinterpret_cast<float*>(ln), sz == 2 ? ln : nullptr, s), "w2v2 projection LayerNorm");
+    {
+        LinearArgs a = general(ln, 512, m->proj_w, m->proj_b, H);
+        a.zero_invalid = 1; a.out32 = X; a.out_rows = xb_out; a.out_ld = H;
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, a, H / 256, s), "w2v2 projection");
+    }
+    {   // positional convolution (+GELU) + residual -> P, then the encoder's LayerNorm
+        LinearArgs a = general(act_x, H, m->pos_w, m->pos_b, H);
+        a.taps = m->taps; a.groups_per_tap = m->gpt; a.real_groups = a.total_groups = m->taps * m->gpt;
+        a.act_y_stride = (H / m->groups) * sz; a.act_fn = 2; a.residual = X; a.out32 = P;
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 3, 1, a, m->groups, s), "w2v2 positional convolution");
+        LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
+    }
+    for (int l = 0; l < m->layers; ++l) {
+        const PpgW2v2Body::Layer& d = m->layer[l];
+        {
+            LinearArgs a = general(act_x, H, d.wqkv, d.bqkv, 3 * H);
+            a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = vt_ld; a.v_start = 2 * H;
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, nt, a, 3 * H / 256, s), "w2v2 qkv");
+        }
+        {
+            AttnArgs a{};
+            a.qk = qk; a.qk_ld_bytes = 2 * H * sz; a.vt = vt; a.vt_ld_bytes = vt_ld * sz;
+            a.ao = ao; a.H = H; a.causal = 0;
+            a.scale_log2e = (float)(1.4426950408889634 / sqrt(64.0));
+            a.items = d_items; a.win = d_win; a.M = M; a.ao_tiled = 0; a.heads = m->heads;
+            LAUNCH_OK(ppg::launch_attn(prec, a, ni, m->heads, 64, s), "w2v2 attention");
+        }
+        {
+            LinearArgs a = general(ao, H, d.wo, d.bo, H);
+            a.residual = X; a.out32 = P;
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, a, H / 256, s), "w2v2 out-proj");
+            LAUNCH_OK(layer_norm(d.g1, d.e1), "w2v2 LayerNorm 1");
+        }
+        {
+            LinearArgs a = general(act_x, H, d.w1, d.b1, F);
+            a.act_fn = 2; a.out_ld32 = F;
+            if (sz == 2) { a.out_rows = hid; a.out_ld = F; } else { a.out32 = reinterpret_cast<float*>(hid); }
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, a, F / 256, s), "w2v2 ffn 1");
+            LinearArgs b = general(hid, F, d.w2, d.b2, H);
+            b.residual = X; b.out32 = P;
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, b, H / 256, s), "w2v2 ffn 2");
+            LAUNCH_OK(layer_norm(d.g2, d.e2), "w2v2 LayerNorm 2");
+        }
+    }
+#undef LAUNCH_OK
+    HIP_OK(hipMemcpy2DAsync(out, (size_t)frames * H * 4, X, (size_t)R * H * 4, (size_t)frames * H * 4, batch, hipMemcpyDeviceToDevice, s));
+    return PPG_OK;
+}
+
 int ppg_frontend(int device, const float* audio, int batch, int samples, void* spec, void* mel, void* stream) {
     if (!audio || (!spec && !mel)) return fail(PPG_EINVAL, "null argument");
     if (batch <= 0) return fail(PPG_EINVAL, "batch %d", batch);

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     // Window lookups (two dependent global loads) only where window positions
     // matter: the k-tap convs.  The plain projections read and write every
     // row below M -- padding rows hold finite values nobody consumes.
-    constexpr bool CONV = EPI == EPI_INCONV || EPI == EPI_OUTCONV;
+    constexpr bool CONV = EPI == EPI_INCONV || EPI == EPI_OUTCONV || EPI == EPI_GENERAL;
     TokMeta tm[NT];
     if constexpr (CONV) {
 #pragma unroll
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                     const int st = tm[t].tt + tap - pad;
                     if (tm[t].w >= 0 && gk < a.real_groups && st >= 0 && st < tm[t].frames) {
                         const int m = tok0 + 16 * t + idx + tap - pad;
-                        v = *reinterpret_cast<const u32x4*>(a.act + (size_t)m * a.lda_bytes + kgi * 64 + g * 16);
+                        const char* act = a.act;
+                        if constexpr (EPI == EPI_GENERAL) act += (size_t)blockIdx.y * a.act_y_stride;
+                        v = *reinterpret_cast<const u32x4*>(act + (size_t)m * a.lda_bytes + kgi * 64 + g * 16);
                     }
                 } else {
                     const int m = tok0 + 16 * t + idx;
@@ -601,6 +603,41 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 if (m >= a.M) continue;
                 pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
                             gelu(acc[nb][t][0]), gelu(acc[nb][t][1]), gelu(acc[nb][t][2]), gelu(acc[nb][t][3]));
+            }
+        }
+    } else if constexpr (EPI == EPI_GENERAL) {
+        // y = act_fn(acc + bias) [zeroed past the window's valid rows] [+ residual] -> fp32 rows and / or 16-bit rows.
+        // NB == 16: W rows in paired order (16-byte stores of the 16-bit copy); other NB: plain order, fp32 output only.
+        auto gelu = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); };
+        PairStore<P> pair[NT];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + (NB == 16 ? pair_feature(nb, g) : nb * 16 + 4 * g);
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int m = tok0 + 16 * t + idx;
+                if (m >= a.M) continue;
+                float y[4] = {acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y, acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w};
+                if (a.act_fn == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = gelu(y[r]);
+                } else if (a.act_fn == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+                }
+                if (a.zero_invalid && !(tm[t].w >= 0 && tm[t].tt < tm[t].valid)) y[0] = y[1] = y[2] = y[3] = 0.f;
+                if (a.residual) {
+                    const float4 rv = *reinterpret_cast<const float4*>(a.residual + (size_t)m * a.out_ld32 + n);
+                    y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
+                }
+                if (a.out32) *reinterpret_cast<float4*>(a.out32 + (size_t)m * a.out_ld32 + n) = make_float4(y[0], y[1], y[2], y[3]);
+                if constexpr (NB == 16) {
+                    if (a.out_rows) {
+                        if constexpr (P::kIsBF16) pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1, y[0], y[1], y[2], y[3]);
+                        else store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes, y[0], y[1], y[2], y[3]);
+                    }
+                }
             }
         }
     } else if constexpr (EPI == EPI_RELU) {
@@ -1557,6 +1594,7 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
     case EPI_QKV:    return launch_linear_nt<P, 16, EPI_QKV>(nt, a, ypasses, s);
     case EPI_RELU:   return launch_linear_nt<P, 16, EPI_RELU>(nt, a, ypasses, s);
     case EPI_GELU:   return launch_linear_nt<P, 16, EPI_GELU>(nt, a, ypasses, s);
+    case EPI_GENERAL: return nb == 3 ? launch_linear_t<P, 1, 3, EPI_GENERAL>(a, ypasses, s) : launch_linear_nt<P, 16, EPI_GENERAL>(nt, a, ypasses, s);
     case EPI_OUTCONV:return launch_linear_nt<P, 3, EPI_OUTCONV>(nt, a, ypasses, s);
     case EPI_RESLN:
         // one 16-token block per wave: the LayerNorm epilogue holds a whole feature row per token in registers
@@ -1629,6 +1667,8 @@ hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim,
         hipLaunchKernelGGL(attn_mixed_kernel<P>, dim3(nitems * heads), dim3(256), 65536, s, a);
     } else if (head_dim == 256) {
         hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems * heads), dim3(256), 65536, s, a);
+    } else if (head_dim == 64) {             // wav2vec2 body: 12 heads of 64
+        hipLaunchKernelGGL((attn_kernel<P, 1, 64>), dim3(nitems * heads), dim3(256), 65536, s, a);
     } else {
         return hipErrorInvalidValue;
     }
@@ -1639,7 +1679,7 @@ hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim,
 
 namespace ppg {
 
-int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }
+int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }   // (d = 64 and d = 256: 16 queries per wave)
 
 // -DPPG_ONLY_BF16: kernel experiments build only the bf16 instantiations (a third of the compile time)
 #ifdef PPG_ONLY_BF16

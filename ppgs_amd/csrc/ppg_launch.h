@@ -28,6 +28,8 @@ int layer32_tokens(int hidden);       // token rows per workgroup (160 at hidden
 hipError_t launch_w2v2_layer0(int precision, const float* audio, int batch, long samples, long frames, int rows_per_item,
                               const float* w0, const float* gamma, const float* beta, double* moments, float2* scale_shift,
                               char* out, hipStream_t s);
+hipError_t launch_w2v2_layernorm(int precision, int H, const float* in32, const char* in16, const float* gamma, const float* beta,
+                                 long rows, int T_in, int R_out, float eps, float* out32, char* out16, hipStream_t s);
 hipError_t launch_w2v2_output(int precision, const char* rows, int batch, int rows_per_item, long frames, float* out, hipStream_t s);
 
 constexpr int kMaxMelWeights = 1536;   // LDS room for the packed filterbank (1001 non-zeros + interior zeros)

@@ -16,6 +16,8 @@
 #include "ppg_device.h"
 #include "ppg_launch.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int W2V_C = 512;
@@ -144,9 +146,74 @@ __global__ __launch_bounds__(256) void w2v2_output_kernel(const char* rows, int 
     *reinterpret_cast<float4*>(out + ((size_t)b * frames + t) * W2V_C + c) = v;
 }
 
+// Row LayerNorm for the transformer body (widths 512 and 768 do not fit the GEMM epilogues' register tiles):
+// one wave per row.  Input fp32 [rows_in][H] (item b's rows b * T_in ..) or operand-type rows; output row
+// (m / T_in) * R_out + m % T_in -- the token space pads every item to R_out rows -- as fp32 and / or operand type.
+template <class P, int H>
+__global__ __launch_bounds__(256) void w2v2_layernorm_kernel(const float* in32, const char* in16, const float* gamma, const float* beta,
+                                                             long rows, int T_in, int R_out, float eps, float* out32, char* out16) {
+    constexpr int PER = H / 64;
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    float v[PER];
+    if (in32) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = in32[m * H + i * 64 + lane];
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if constexpr (P::kIsBF16) {
+                const uint16_t raw = reinterpret_cast<const uint16_t*>(in16)[m * H + i * 64 + lane];
+                if constexpr (std::is_same_v<P, PrecBF16>) v[i] = bf16_to_f32(raw);
+                else v[i] = (float)__builtin_bit_cast(_Float16, raw);
+            } else {
+                v[i] = reinterpret_cast<const float*>(in16)[m * H + i * 64 + lane];
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) sum += v[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; sq += d * d; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / H + eps);
+    const long mo = (m / T_in) * R_out + m % T_in;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int n = i * 64 + lane;
+        const float y = (v[i] - mean) * rstd * gamma[n] + beta[n];
+        if (out32) out32[mo * H + n] = y;
+        if (out16) reinterpret_cast<typename P::elem*>(out16)[mo * H + n] = P::cvt1(y);
+    }
+}
+
 }  // namespace
 
 namespace ppg {
+
+hipError_t launch_w2v2_layernorm(int precision, int H, const float* in32, const char* in16, const float* gamma, const float* beta,
+                                 long rows, int T_in, int R_out, float eps, float* out32, char* out16, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    auto go = [&](auto p_tag) {
+        using P = decltype(p_tag);
+        if (H == 512) hipLaunchKernelGGL((w2v2_layernorm_kernel<P, 512>), grid, dim3(256), 0, s, in32, in16, gamma, beta, rows, T_in, R_out, eps, out32, out16);
+        else if (H == 768) hipLaunchKernelGGL((w2v2_layernorm_kernel<P, 768>), grid, dim3(256), 0, s, in32, in16, gamma, beta, rows, T_in, R_out, eps, out32, out16);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    };
+    if (precision == PPG_PRECISION_BF16) return go(PrecBF16{});
+    if (precision == PPG_PRECISION_FP16) return go(PrecF16{});
+    return go(PrecF32{});
+}
+
 
 hipError_t launch_w2v2_layer0(int precision, const float* audio, int batch, long samples, long frames, int rows_per_item,
                               const float* w0, const float* gamma, const float* beta, double* moments, float2* scale_shift,

@@ -52,6 +52,24 @@ class PpgWindow(ctypes.Structure):
         'out_frame', 'tok_off', 'vt_off', 'pad0', 'pad1')]
 
 
+class PpgW2v2LayerWeights(ctypes.Structure):
+    _fields_ = [(name, ctypes.POINTER(ctypes.c_float)) for name in (
+        'q_weight', 'q_bias', 'k_weight', 'k_bias', 'v_weight', 'v_bias', 'out_weight', 'out_bias',
+        'norm1_weight', 'norm1_bias', 'ffn1_weight', 'ffn1_bias', 'ffn2_weight', 'ffn2_bias',
+        'norm2_weight', 'norm2_bias')]
+
+
+class PpgW2v2BodyWeights(ctypes.Structure):
+    _fields_ = [
+        ('hidden', ctypes.c_int32), ('heads', ctypes.c_int32), ('ffn', ctypes.c_int32),
+        ('num_layers', ctypes.c_int32), ('conv_kernel', ctypes.c_int32), ('conv_groups', ctypes.c_int32),
+        ('layer_norm_eps', ctypes.c_float), ('pad0', ctypes.c_int32)] + [
+        (name, ctypes.POINTER(ctypes.c_float)) for name in (
+            'proj_norm_weight', 'proj_norm_bias', 'proj_weight', 'proj_bias',
+            'pos_conv_weight', 'pos_conv_bias', 'enc_norm_weight', 'enc_norm_bias')] + [
+        ('layers', PpgW2v2LayerWeights * 24)]
+
+
 class PpgAttentionItem(ctypes.Structure):
     _fields_ = [(name, ctypes.c_int32) for name in (
         'window', 'q0', 'queries', 'frames', 'valid', 'narrow')]
@@ -105,6 +123,14 @@ SYMBOLS = {
     'ppg_grid_sample': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'ppg_w2v2_body_create': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'ppg_w2v2_body_destroy': (None, [ctypes.c_void_p]),
+    'ppg_w2v2_body_workspace_bytes': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    'ppg_w2v2_body_forward': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, _I64P, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'ppg_stream_create': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'ppg_stream_destroy': (None, [ctypes.c_void_p]),
@@ -664,6 +690,86 @@ class W2v2FeatureEncoder:
             out = torch.empty((batch, frames, 512), dtype=torch.float32, device=self.device)
             _check(self._lib.ppg_w2v2_features(
                 self._handle, audio.data_ptr(), batch, samples, out.data_ptr(),
+                workspace.data_ptr(), workspace.numel(), stream))
+        return out
+
+
+class W2v2Body:
+    """The wav2vec 2.0 transformer body on the HIP engine (ppg_w2v2_body_*): HF
+    ``Wav2Vec2Model``'s ``feature_projection`` + ``encoder`` (post-norm layers, grouped
+    positional convolution), built from the HF module's parameters."""
+
+    def __init__(self, model, device=0, precision='fp16'):
+        if not torch.cuda.is_available():
+            raise PpgError('ppgs_amd: no HIP device visible; the engine has no CPU path')
+        lib = library()
+        cfg = model.config
+        if getattr(cfg, 'do_stable_layer_norm', False):
+            raise ValueError('the HIP wav2vec2 body implements the post-norm encoder (do_stable_layer_norm = False)')
+        keep = []
+
+        def ptr(tensor):
+            tensor = tensor.detach().to('cpu', torch.float32).contiguous()
+            keep.append(tensor)
+            return ctypes.cast(tensor.data_ptr(), _FP)
+        wts = PpgW2v2BodyWeights()
+        wts.hidden, wts.heads, wts.ffn = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        wts.num_layers = len(model.encoder.layers)
+        wts.conv_kernel, wts.conv_groups = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        wts.layer_norm_eps = cfg.layer_norm_eps
+        projection, encoder = model.feature_projection, model.encoder
+        wts.proj_norm_weight, wts.proj_norm_bias = ptr(projection.layer_norm.weight), ptr(projection.layer_norm.bias)
+        wts.proj_weight, wts.proj_bias = ptr(projection.projection.weight), ptr(projection.projection.bias)
+        conv = encoder.pos_conv_embed.conv
+        wts.pos_conv_weight, wts.pos_conv_bias = ptr(conv.weight), ptr(conv.bias)      # .weight: weight norm applied
+        wts.enc_norm_weight, wts.enc_norm_bias = ptr(encoder.layer_norm.weight), ptr(encoder.layer_norm.bias)
+        for index, layer in enumerate(encoder.layers):
+            lw, attn = wts.layers[index], layer.attention
+            lw.q_weight, lw.q_bias = ptr(attn.q_proj.weight), ptr(attn.q_proj.bias)
+            lw.k_weight, lw.k_bias = ptr(attn.k_proj.weight), ptr(attn.k_proj.bias)
+            lw.v_weight, lw.v_bias = ptr(attn.v_proj.weight), ptr(attn.v_proj.bias)
+            lw.out_weight, lw.out_bias = ptr(attn.out_proj.weight), ptr(attn.out_proj.bias)
+            lw.norm1_weight, lw.norm1_bias = ptr(layer.layer_norm.weight), ptr(layer.layer_norm.bias)
+            lw.ffn1_weight = ptr(layer.feed_forward.intermediate_dense.weight)
+            lw.ffn1_bias = ptr(layer.feed_forward.intermediate_dense.bias)
+            lw.ffn2_weight = ptr(layer.feed_forward.output_dense.weight)
+            lw.ffn2_bias = ptr(layer.feed_forward.output_dense.bias)
+            lw.norm2_weight, lw.norm2_bias = ptr(layer.final_layer_norm.weight), ptr(layer.final_layer_norm.bias)
+        handle = ctypes.c_void_p()
+        _check(lib.ppg_w2v2_body_create(
+            ctypes.byref(wts), PRECISIONS[precision], device, ctypes.byref(handle)))
+        self._handle, self._lib = handle, lib
+        self.device = torch.device('cuda', device)
+        self.precision = precision
+        self.hidden = cfg.hidden_size
+        self._workspaces = {}
+
+    def __del__(self):
+        handle = getattr(self, '_handle', None)
+        if handle:
+            self._lib.ppg_w2v2_body_destroy(handle)
+            self._handle = None
+
+    def __call__(self, features, valid_frames):
+        """features (batch, frames, 512) fp32 on this GPU (HF ``extract_features``), valid frames
+        per item (HF's frame-level attention mask as lengths) -> ``last_hidden_state``
+        (batch, frames, hidden) fp32."""
+        if features.dim() != 3 or features.shape[2] != 512:
+            raise ValueError(f'features must be (batch, frames, 512), got {tuple(features.shape)}')
+        features = features.to(self.device, torch.float32).contiguous()
+        batch, frames, _ = features.shape
+        arr = _lengths_array(valid_frames, batch)
+        size = ctypes.c_size_t()
+        _check(self._lib.ppg_w2v2_body_workspace_bytes(self._handle, batch, frames, ctypes.byref(size)))
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            workspace = self._workspaces.get(stream)
+            if workspace is None or workspace.numel() < size.value:
+                workspace = torch.empty(size.value, dtype=torch.uint8, device=self.device)
+                self._workspaces[stream] = workspace
+            out = torch.empty((batch, frames, self.hidden), dtype=torch.float32, device=self.device)
+            _check(self._lib.ppg_w2v2_body_forward(
+                self._handle, features.data_ptr(), arr, batch, frames, out.data_ptr(),
                 workspace.data_ptr(), workspace.numel(), stream))
         return out
 

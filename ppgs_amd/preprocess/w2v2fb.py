@@ -2,14 +2,16 @@
 ppgs/preprocess/w2v2fb/core.py:32-75.
 
 The reference delegates the body to the third-party HF ``Wav2Vec2Model``
-('facebook/wav2vec2-base').  Here the model's convolutional feature encoder
-(7 strided convolutions, GroupNorm, GELU: most of the audio-rate work) runs in
-the hand-written HIP engine (``engine.W2v2FeatureEncoder``, ppg_w2v2.hip +
-linear_kernel<EPI_GELU>); the feature projection and the 12-layer transformer
-still run as the HF modules on the HIP device through stock PyTorch-ROCm ops
-(in progress).  Everything after the latents -- the
-768-channel, hidden-512 PPG network -- runs in the HIP engine.
-PPGS_AMD_W2V2_NATIVE=0 runs the whole HF model through PyTorch-ROCm.
+('facebook/wav2vec2-base').  Here the whole model runs in the hand-written HIP
+engine: the convolutional feature encoder (7 strided convolutions, GroupNorm,
+GELU; ``engine.W2v2FeatureEncoder``, ppg_w2v2.hip + linear_kernel<EPI_GELU>)
+and the feature projection + 12-layer transformer (``engine.W2v2Body``:
+linear_kernel<EPI_GENERAL>, attention at head dimension 64, row LayerNorms,
+the grouped positional convolution as 16 GEMMs of one launch) -- SURVEY.md
+8(f) rank 1.  Everything after the latents -- the 768-channel, hidden-512 PPG
+network -- runs in the HIP engine too.  PPGS_AMD_W2V2_BODY=0 keeps the HF
+projection / encoder modules on PyTorch-ROCm, PPGS_AMD_W2V2_NATIVE=0 runs the
+whole HF model there.
 
 Same arithmetic as the reference: zero-pad 40 samples each side, attention
 mask over the first ``length + 80`` samples, ``last_hidden_state`` (B, ~T/2,
@@ -59,6 +61,18 @@ def feature_encoder_for(device, model):
     return _encoders[key]
 
 
+_bodies = {}
+
+
+def body_for(device, model):
+    """Cached HIP transformer body holding `model`'s projection / encoder weights."""
+    from .. import core, engine
+    key = (str(device), id(model), core.PRECISION)
+    if key not in _bodies:
+        _bodies[key] = engine.W2v2Body(model, device.index, core.PRECISION)
+    return _bodies[key]
+
+
 def last_hidden_state(model, padded, mask):
     """HF ``Wav2Vec2Model.forward`` (modeling_wav2vec2.py) with the feature
     encoder replaced by the HIP kernels: extract_features -> frame-rate
@@ -69,8 +83,12 @@ def last_hidden_state(model, padded, mask):
     extract = feature_encoder_for(padded.device, model)(padded)
     attention_mask = model._get_feature_vector_attention_mask(
         extract.shape[1], mask, add_adapter=False)
-    # the projection and the transformer are still the HF modules: in the 16-bit engine modes they
-    # run under fp16 autocast, which is how the reference itself runs the whole model on a GPU
+    if os.environ.get('PPGS_AMD_W2V2_BODY', '1') != '0':
+        # feature projection + encoder on the HIP engine (engine.W2v2Body): the frame-level mask is a
+        # prefix mask, i.e. a valid length per item
+        return body_for(padded.device, model)(extract, attention_mask.sum(dim=1))
+    # PPGS_AMD_W2V2_BODY=0: the HF modules on PyTorch-ROCm; in the 16-bit engine modes under fp16
+    # autocast, which is how the reference itself runs the whole model on a GPU
     # (ppgs/preprocess/core.py:207: torch.autocast('cuda')); fp32 engine mode: fp32 throughout
     with torch.autocast('cuda', dtype=torch.float16, enabled=core.PRECISION != 'fp32'):
         hidden, _ = model.feature_projection(extract)
