@@ -428,3 +428,62 @@ def w2v2_feature_encoder(state, audio):
                 state['conv_layers.0.layer_norm.bias'], 1e-5)
         x = torch.nn.functional.gelu(x)
     return x.transpose(1, 2)
+
+
+def w2v2_body(state, features, valid, heads=12, eps=1e-5):
+    """HF transformers ``Wav2Vec2Model.forward`` after the feature encoder, restated (the
+    third-party body reference ppgs/preprocess/w2v2fb/core.py:66 runs; models/wav2vec2/
+    modeling_wav2vec2.py): Wav2Vec2FeatureProjection (LayerNorm 512, Linear 512 -> hidden),
+    Wav2Vec2Encoder with do_stable_layer_norm = False (rows outside the frame-level
+    attention mask zeroed, Wav2Vec2PositionalConvEmbedding = weight-normed Conv1d k = 128,
+    padding 64, 16 groups, last output dropped, GELU; residual; LayerNorm) and its
+    Wav2Vec2EncoderLayers (self-attention with q scaled by d^-0.5 and padded keys masked,
+    residual, LayerNorm, Linear-GELU-Linear, residual, LayerNorm).
+    features (B, T, 512) fp32, valid: frames of each item inside the mask ->
+    last_hidden_state (B, T, hidden) fp32.  `state` = the model's state dict.  Pinned by
+    tests/golden/g12_w2v2_body.npz, the output of the HF modules themselves
+    (oracle/make_golden_w2v2_body.py)."""
+    F = torch.nn.functional
+    x = features.to(torch.float)
+    B, T, _ = x.shape
+    mask = torch.arange(T)[None] < torch.as_tensor(valid).reshape(-1, 1)           # (B, T)
+    x = F.layer_norm(x, (x.shape[-1],), state['feature_projection.layer_norm.weight'],
+                     state['feature_projection.layer_norm.bias'], eps)
+    x = F.linear(x, state['feature_projection.projection.weight'], state['feature_projection.projection.bias'])
+    x = x * mask[..., None]
+    prefix = 'encoder.pos_conv_embed.conv.'
+    if prefix + 'weight' in state:
+        weight = state[prefix + 'weight']
+    else:                                                                           # weight norm over dims (0, 1): one gain per tap
+        g_key = prefix + ('parametrizations.weight.original0' if prefix + 'parametrizations.weight.original0' in state else 'weight_g')
+        v_key = prefix + ('parametrizations.weight.original1' if prefix + 'parametrizations.weight.original1' in state else 'weight_v')
+        v = state[v_key]
+        weight = state[g_key] * v / v.norm(dim=(0, 1), keepdim=True)
+    kernel = weight.shape[-1]
+    groups = x.shape[-1] // weight.shape[1]
+    pos = F.conv1d(x.transpose(1, 2), weight, state[prefix + 'bias'], padding=kernel // 2, groups=groups)
+    if kernel % 2 == 0:
+        pos = pos[..., :-1]
+    x = x + F.gelu(pos).transpose(1, 2)
+    x = F.layer_norm(x, (x.shape[-1],), state['encoder.layer_norm.weight'], state['encoder.layer_norm.bias'], eps)
+    hidden = x.shape[-1]
+    d = hidden // heads
+    bias = torch.zeros(B, 1, 1, T)
+    bias.masked_fill_(~mask[:, None, None, :], torch.finfo(torch.float).min)
+    layer = 0
+    while f'encoder.layers.{layer}.attention.q_proj.weight' in state:
+        p = f'encoder.layers.{layer}.'
+        def lin(name, v):
+            return F.linear(v, state[p + name + '.weight'], state[p + name + '.bias'])
+        q = (lin('attention.q_proj', x) * d ** -0.5).view(B, T, heads, d).transpose(1, 2)
+        k = lin('attention.k_proj', x).view(B, T, heads, d).transpose(1, 2)
+        v = lin('attention.v_proj', x).view(B, T, heads, d).transpose(1, 2)
+        weights = torch.softmax(q @ k.transpose(-1, -2) + bias, dim=-1)
+        attn = (weights @ v).transpose(1, 2).reshape(B, T, hidden)
+        x = x + lin('attention.out_proj', attn)
+        x = F.layer_norm(x, (hidden,), state[p + 'layer_norm.weight'], state[p + 'layer_norm.bias'], eps)
+        x = x + lin('feed_forward.output_dense', F.gelu(lin('feed_forward.intermediate_dense', x)))
+        x = F.layer_norm(x, (hidden,), state[p + 'final_layer_norm.weight'], state[p + 'final_layer_norm.bias'], eps)
+        layer += 1
+    return x
+

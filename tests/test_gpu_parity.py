@@ -867,10 +867,42 @@ def test_w2v2_feature_encoder_vs_hf_fixture(golden):
         encoder(torch.zeros(1, 300).cuda())
 
 
+def test_w2v2_body_vs_hf_fixture(golden):
+    """ppg_w2v2_body_forward (feature projection, grouped positional convolution, 12 post-norm layers
+    with attention at head dimension 64) against the output of HF's own modules (fixture G12) on the
+    rows inside the frame-level mask: fp32 mode 1e-4 on activations of magnitude ~4.5; fp16 operands
+    1e-2; bf16 6e-2.  Ragged valid lengths (70, 47, 9 of 70 frames); workspace contents must not matter."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    from oracle import make_golden_w2v2 as M
+    from oracle import make_golden_w2v2_body as MB
+    g = golden('g12_w2v2_body')
+    model = M.seeded_model(int(g['seed']))
+    if abs(MB.body_checksum(model) - float(g['checksum'])) > 1e-6 * float(g['checksum']):
+        pytest.skip('this torch / transformers build seeds the HF model differently from the fixture')
+    features, valid, ref = t(g['features']).cuda(), g['valid'].tolist(), g['last_hidden_state']
+    for precision, tol in (('fp32', 1e-4), ('fp16', 1e-2), ('bf16', 6e-2)):
+        body = E.W2v2Body(model, 0, precision)
+        out = body(features, valid)
+        torch.cuda.synchronize()
+        assert out.shape == (3, 70, 768) and torch.isfinite(out).all()
+        for item, frames in enumerate(valid):
+            assert np.abs(out[item, :frames].cpu().numpy() - ref[item, :frames]).max() < tol, (precision, item)
+        for workspace in body._workspaces.values():
+            workspace.fill_(255)
+        assert torch.equal(out, body(features, valid))
+    with pytest.raises(ValueError):
+        body(features, [71, 1, 1])
+    with pytest.raises(ValueError):
+        body(features[:, :, :100], valid)
+
+
 def test_w2v2fb_representation_native_vs_pytorch(golden, monkeypatch):
     """The w2v2fb representation end to end (reference ppgs/preprocess/w2v2fb/core.py:32-75: pad 40,
-    sample mask, Wav2Vec2Model, nearest upsampling, fp16) with the HIP feature encoder against the
-    same HF model run entirely by PyTorch-ROCm, and against the fixture's last_hidden_state."""
+    sample mask, Wav2Vec2Model, nearest upsampling, fp16) with the HIP feature encoder AND the HIP
+    transformer body against the same HF model run entirely by PyTorch-ROCm (also with only the
+    body on PyTorch: PPGS_AMD_W2V2_BODY=0), and against the fixture's last_hidden_state."""
     g, model = _seeded_w2v2(golden)
     from ppgs_amd.preprocess import w2v2fb
     device = torch.device('cuda', 0)
@@ -884,6 +916,12 @@ def test_w2v2fb_representation_native_vs_pytorch(golden, monkeypatch):
     stock = w2v2fb.from_audios(audio, lengths, gpu=0)
     assert native.shape == stock.shape == (3, 768, 37) and native.dtype == torch.float16
     assert (native.float() - stock.float()).abs().max() < 5e-3
+    monkeypatch.delenv('PPGS_AMD_W2V2_NATIVE')
+    monkeypatch.setenv('PPGS_AMD_W2V2_BODY', '0')
+    hybrid = w2v2fb.from_audios(audio, lengths, gpu=0)
+    monkeypatch.delenv('PPGS_AMD_W2V2_BODY')
+    monkeypatch.setenv('PPGS_AMD_W2V2_NATIVE', '0')
+    assert (hybrid.float() - stock.float()).abs().max() < 5e-3 and not torch.equal(hybrid, native)
     # unpadded, unmasked input through the model = the fixture's last_hidden_state
     monkeypatch.delenv('PPGS_AMD_W2V2_NATIVE')
     with torch.no_grad():

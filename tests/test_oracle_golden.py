@@ -212,3 +212,23 @@ def test_g11_w2v2_feature_encoder_matches_hf(golden):
     out = O.w2v2_feature_encoder(state, t(g['audio'])).numpy()
     assert out.shape == g['features'].shape == (3, 18, 512)
     assert np.abs(out - g['features']).max() < 1e-5
+
+
+def test_g12_w2v2_body_matches_hf(golden):
+    """The restatement of HF's feature projection + encoder (frame-level attention mask, grouped
+    positional convolution with weight norm, 12 post-norm layers) against the modules' own
+    output (fixture G12, seeded random weights of the base architecture rebuilt here)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    from oracle import make_golden_w2v2 as M
+    from oracle import make_golden_w2v2_body as MB
+    g = golden('g12_w2v2_body')
+    model = M.seeded_model(int(g['seed']))
+    assert abs(MB.body_checksum(model) - float(g['checksum'])) < 1e-6 * float(g['checksum'])
+    valid = g['valid'].tolist()
+    out = O.w2v2_body(model.state_dict(), t(g['features']), valid).numpy()
+    assert out.shape == g['last_hidden_state'].shape == (3, 70, 768)
+    for item, frames in enumerate(valid):                        # rows inside the mask (the others are never used)
+        assert np.abs(out[item, :frames] - g['last_hidden_state'][item, :frames]).max() < 2e-5
+
