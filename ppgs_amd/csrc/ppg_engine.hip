@@ -1862,7 +1862,9 @@ int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* 
         hipError_t he_ = (expr);                                                     \
         if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
     } while (0)
-    const int nt = std::min(choose_nt(E, M, 2), 2);
+    // tokens per wave (16 nt).  Measured at 16 x 499 frames, bf16: nt 1 4.41 ms, nt 2 4.82 ms, nt 3 6.35 ms
+    int nt = std::min(choose_nt(E, M, 2), 2);
+    if (const char* v = getenv("PPGS_AMD_W2V2_NT")) nt = std::max(1, std::min(atoi(v), sz == 2 ? 3 : 2));
     auto general = [&](const char* act, int k_elems, const char* W, const float* bias, int N) {
         LinearArgs a{};
         a.blk_win = d_blk; a.win = d_win; a.M = M; a.H = H; a.v_start = INT_MAX; a.taps = 1;
