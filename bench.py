@@ -265,6 +265,23 @@ def run_c2(args, rank, world, local_rank, use_dist):
                'value': BATCH * FRAMES * args.steps / alt_elapsed,
                'max_abs_vs_bf16': float((alt_out - out).abs().max())}
         del other
+    alt_streams = None
+    if rank == 0 and world == 1 and not args.no_alt and 'PPGS_AMD_STREAMS' not in os.environ:
+        # the same step with the batch split into two half-batches on two HIP streams of one engine: one half's
+        # memory-bound phases run beside the other half's MFMA phases.  Not the default configuration: kernels of the
+        # two halves overlap, so no per-kernel duration (no roofline fraction) can be read off such a run.
+        os.environ['PPGS_AMD_STREAMS'] = '2'
+        try:
+            other = E.Engine(state, local_rank, args.precision)
+        finally:
+            del os.environ['PPGS_AMD_STREAMS']
+        for _ in range(max(args.warmup, 3)):
+            step(other)
+        s2_elapsed, s2_out = timed_block(other)
+        alt_streams = {'streams': 2, 'ms_per_step': 1e3 * s2_elapsed / args.steps,
+                       'value': BATCH * FRAMES * args.steps / s2_elapsed,
+                       'max_abs_vs_one_stream': float((s2_out - out).abs().max())}
+        del other
 
     if rank != 0:
         return None
@@ -326,6 +343,8 @@ def run_c2(args, rank, world, local_rank, use_dist):
     }
     if alt:
         line['alt_precision'] = alt
+    if alt_streams:
+        line['alt_streams'] = alt_streams
     if world == 1 and not args.no_cpu:
         line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
         line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
