@@ -898,6 +898,46 @@ def test_w2v2_body_vs_hf_fixture(golden):
         body(features[:, :, :100], valid)
 
 
+def test_w2v2_body_shapes_vs_hf_modules():
+    """The HIP body against the HF modules on the same GPU (2-layer model of the base width, seeded)
+    at the sizes the fixture does not reach: 30 s of audio (1499 frames, 24 key tiles), single-frame
+    items, a batch of one-frame items, ragged masks."""
+    import transformers
+    transformers.utils.logging.set_verbosity_error()
+    torch.manual_seed(5)
+    model = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(num_hidden_layers=2)).eval().cuda()
+    body = E.W2v2Body(model, 0, 'fp32')
+    gen = torch.Generator().manual_seed(3)
+    for shape, valid in (((1, 1499, 512), [1499]), ((2, 33, 512), [33, 1]), ((5, 1, 512), [1] * 5),
+                         ((3, 257, 512), [257, 200, 129])):
+        x = torch.randn(*shape, generator=gen).cuda()
+        frames = shape[1]
+        mask = torch.arange(frames, device='cuda')[None] < torch.tensor(valid, device='cuda')[:, None]
+        with torch.no_grad():
+            hidden, _ = model.feature_projection(x)
+            ref = model.encoder(hidden, attention_mask=mask).last_hidden_state
+        out = body(x, valid)
+        for item, count in enumerate(valid):
+            assert (out[item, :count] - ref[item, :count]).abs().max() < 1e-4, (shape, item)
+
+
+@pytest.mark.parametrize('capacity,total,step', [(40, 40, 1), (17, 9, 2), (500, 500, 125), (64, 3, 3)])
+def test_kv_cached_stream_edges(capacity, total, step):
+    """Streams at the edges: one-frame pushes, fewer frames than the convolutions' look-ahead before
+    the flush, a full 500-frame window, fp32 features."""
+    engine, state = eng(causal=True)
+    gen = torch.Generator().manual_seed(77)
+    feats = torch.randn(80, total, generator=gen)
+    ref = O.from_features(state, feats[None], torch.tensor([total]), is_causal=True).numpy()[0]
+    stream = engine.stream(capacity, torch.float32)
+    pieces = [stream.push(feats[:, i:i + step].cuda()) for i in range(0, total, step)]
+    pieces.append(stream.push(None, flush=True))
+    out = torch.cat(pieces, dim=1).cpu().numpy()
+    assert out.shape == (40, total) and np.abs(out - ref).max() < FP32_TOL
+    with pytest.raises(ValueError):
+        engine.stream(capacity).push(torch.zeros(80, capacity + 1).cuda())
+
+
 def test_w2v2fb_representation_native_vs_pytorch(golden, monkeypatch):
     """The w2v2fb representation end to end (reference ppgs/preprocess/w2v2fb/core.py:32-75: pad 40,
     sample mask, Wav2Vec2Model, nearest upsampling, fp16) with the HIP feature encoder AND the HIP
