@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     } else if constexpr (EPI == EPI_GELU) {
         // exact GELU (erf form, torch.nn.functional.gelu default); W rows in paired order: 16-byte stores
         PairStore<P> pair[NT];
-        auto gelu = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); };
+        auto gelu = [](float x) { return gelu_erf(x); };
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = n0 + pair_feature(nb, g);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     } else if constexpr (EPI == EPI_GENERAL) {
         // y = act_fn(acc + bias) [zeroed past the window's valid rows] [+ residual] -> fp32 rows and / or 16-bit rows.
         // NB == 16: W rows in paired order (16-byte stores of the 16-bit copy); other NB: plain order, fp32 output only.
-        auto gelu = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); };
+        auto gelu = [](float x) { return gelu_erf(x); };
         PairStore<P> pair[NT];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

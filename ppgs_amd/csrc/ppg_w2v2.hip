@@ -22,7 +22,7 @@ namespace {
 
 constexpr int W2V_C = 512;
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_exact(float x) { return gelu_erf(x); }
 
 // moments[b][0..9] = M1, [10..64] = upper triangle of M2 (j <= k, row-major)
 __global__ __launch_bounds__(256) void w2v2_moments_kernel(const float* audio, long samples, long frames, double* moments) {
