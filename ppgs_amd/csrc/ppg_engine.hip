@@ -275,6 +275,7 @@ struct PpgEngine {
     std::vector<hipStream_t> side_streams;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
+    int l32_debug = 0, h32_debug = 0;         // PPGS_AMD_L32_DEBUG / PPGS_AMD_H32_DEBUG: phase-skipping switches of the timing experiments (wrong results), read once
     unsigned long long* ffn_dbg = nullptr;
     unsigned long long* head_dbg = nullptr;
     unsigned long long* attn_dbg = nullptr;  // PPGS_AMD_ATTN_TIMING (PPG_ATTN_TIMING builds)
@@ -838,6 +839,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) e->l32_debug = atoi(v);
+    if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) e->h32_debug = atoi(v);
     if (!e->layer32 || H != 256 || e->Cp != 96 || !e->qkv_fused) e->head32 = false;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
@@ -1126,7 +1129,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.tiles = (M + ppg::layer32_tokens(H) - 1) / ppg::layer32_tokens(H);
         a.nwin = (int)grp.windows.size(); a.vt_rows = H; a.vt_tokens = grp.vt_tokens;
         a.qk_slack = qk + (size_t)M * 2 * H * e->sz; a.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
-        if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) a.debug_mode = atoi(v);
+        a.debug_mode = e->h32_debug;
         a.dbg = e->head_dbg;
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
@@ -1189,7 +1192,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.ao = ao; a.wo_img = d.wo_img; a.w1_img = d.w1_img; a.w2_img = d.w2_img;
             a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2;
             a.X = X; a.Xb = Xb; a.M = M; a.F = F; a.H = H; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
-            if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) a.debug_mode = atoi(v);
+            a.debug_mode = e->l32_debug;
             qkv_done = e->qkv_fused && l + 1 < c.num_layers;
             a.write_x = l + 1 < c.num_layers;
             if (qkv_done) {
