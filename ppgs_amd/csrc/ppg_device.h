@@ -468,3 +468,16 @@ struct Head32Args {
     int debug_mode;           // timing experiments (wrong results): 1 no convolution, 2 no Q/K/V, 4 no gather
     unsigned long long* dbg;  // PPGS_AMD_H32_TIMING=1: s_memtime stamps of workgroup 0, [wave][16]
 };
+
+// ppg_gemm32.hip: Y = act_fn(X W^T + bias) [+ residual], 160 rows x 256 features per workgroup
+struct Gemm32Args {
+    const char* x;            // [M][K] 16-bit, row-major
+    const char* w_img;        // A fragments [N / 256][wave][K / 128][rb][8 K-steps] of 1 KiB (rows in accumulator order phi)
+    const float* bias;        // [N]
+    const float* residual;    // fp32 [M][N] or null
+    float* out32;             // fp32 [M][N] or null
+    char* out16;              // 16-bit [M][N] or null
+    int M, N, K;              // N % 256 == 0, K % 128 == 0
+    int act_fn;               // 0 none, 1 ReLU, 2 GELU
+};
+

@@ -1677,7 +1677,9 @@ struct PpgW2v2Body {
     char* proj_w = nullptr; float* proj_b = nullptr;
     char* pos_w = nullptr; float* pos_b = nullptr;
     float* en_g = nullptr; float* en_b = nullptr;
-    struct Layer { char* wqkv; float* bqkv; char* wo; float* bo; float* g1; float* e1; char* w1; float* b1; char* w2; float* b2; float* g2; float* e2; };
+    struct Layer { char* wqkv; float* bqkv; char* wo; float* bo; float* g1; float* e1; char* w1; float* b1; char* w2; float* b2; float* g2; float* e2;
+                   char* wo_img; char* w1_img; char* w2_img; };   // fragment images for ppg_gemm32.hip (16-bit modes)
+    bool gemm32 = true;            // PPGS_AMD_W2V2_GEMM32=0: linear_kernel<EPI_GENERAL> for every projection
     std::vector<Layer> layer;
     char* staging = nullptr;       // pinned: window / block / item tables of the call in flight
     size_t staging_bytes = 0;
@@ -1712,6 +1714,8 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     E->num_cus = prop.multiProcessorCount;
     m->hidden = H; m->heads = w->heads; m->ffn = F; m->layers = L; m->taps = w->conv_kernel; m->groups = w->conv_groups;
     m->eps = w->layer_norm_eps;
+    if (const char* v = getenv("PPGS_AMD_W2V2_GEMM32")) m->gemm32 = atoi(v) != 0;
+    if (E->sz != 2 || H % 256 || F % 256 || H % 128 || F % 128) m->gemm32 = false;
     const int CG = H / w->conv_groups;                       // 48 channels per group
     m->gpt = (CG * E->sz + 63) / 64;                         // K-groups of 64 bytes per tap: 2 (16-bit, padded) or 3 (fp32)
     int rc;
@@ -1766,6 +1770,24 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
         if ((rc = upload_f32(E, lw.ffn2_bias, H, 0, &d.b2))) return rc;
         if ((rc = upload_f32(E, lw.norm2_weight, H, 0, &d.g2))) return rc;
         if ((rc = upload_f32(E, lw.norm2_bias, H, 0, &d.e2))) return rc;
+        d.wo_img = d.w1_img = d.w2_img = nullptr;
+        if (m->gemm32) {
+            // [N / 256][wave][K / 128][rb][8 K-steps] fragments: lane l = (row phi(l & 31) of the block, k 8 (l >> 5) .. + 7)
+            auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+            auto image = [&](const float* src, int N, int K, char** dst) {
+                const int chunks = K / 128, frags = (N / 256) * 4 * chunks * 16;
+                return upload_matrix(E, frags * 64, 8, frags * 64, 8,
+                                     [&](int r, int j) {
+                                         const int f = r >> 6, ln = r & 63;
+                                         const int ks = f & 7, rb = (f >> 3) & 1, c = (f >> 4) % chunks, wv = ((f >> 4) / chunks) & 3, p = (f >> 4) / chunks / 4;
+                                         const int n = 256 * p + 64 * wv + 32 * rb + phi(ln & 31), k = 128 * c + 16 * ks + 8 * (ln >> 5) + j;
+                                         return src[(size_t)n * K + k];
+                                     }, dst);
+            };
+            if ((rc = image(lw.out_weight, H, H, &d.wo_img))) return rc;
+            if ((rc = image(lw.ffn1_weight, F, H, &d.w1_img))) return rc;
+            if ((rc = image(lw.ffn2_weight, H, F, &d.w2_img))) return rc;
+        }
     }
 #undef NEED
     HIP_OK(hipEventCreateWithFlags(&m->uploaded, hipEventDisableTiming));
@@ -1908,6 +1930,20 @@ int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* 
             a.scale_log2e = (float)(1.4426950408889634 / sqrt(64.0));
             a.items = d_items; a.win = d_win; a.M = M; a.ao_tiled = 0; a.heads = m->heads;
             LAUNCH_OK(ppg::launch_attn(prec, a, ni, m->heads, 64, s), "w2v2 attention");
+        }
+        if (m->gemm32) {
+            Gemm32Args g{};
+            g.x = ao; g.w_img = d.wo_img; g.bias = d.bo; g.residual = X; g.out32 = P; g.M = M; g.N = H; g.K = H;
+            LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 out-proj");
+            LAUNCH_OK(layer_norm(d.g1, d.e1), "w2v2 LayerNorm 1");
+            Gemm32Args f1{};
+            f1.x = Xb; f1.w_img = d.w1_img; f1.bias = d.b1; f1.out16 = hid; f1.M = M; f1.N = F; f1.K = H; f1.act_fn = 2;
+            LAUNCH_OK(ppg::launch_gemm32(prec, f1, s), "w2v2 ffn 1");
+            Gemm32Args f2{};
+            f2.x = hid; f2.w_img = d.w2_img; f2.bias = d.b2; f2.residual = X; f2.out32 = P; f2.M = M; f2.N = H; f2.K = F;
+            LAUNCH_OK(ppg::launch_gemm32(prec, f2, s), "w2v2 ffn 2");
+            LAUNCH_OK(layer_norm(d.g2, d.e2), "w2v2 LayerNorm 2");
+            continue;
         }
         {
             LinearArgs a = general(ao, H, d.wo, d.bo, H);
