@@ -324,6 +324,11 @@ class Engine:
         (see Stream); the engine must be causal."""
         return Stream(self, max_frames, dtype)
 
+    def long_stream(self, dtype=torch.float16):
+        """A KV-cached causal stream over an utterance of any length > 500 frames
+        (see LongStream); the engine must be causal."""
+        return LongStream(self, dtype)
+
     def encode(self, features, lengths, softmax=True, legacy_mode=False,
                workspace=None):
         """features (B, Cin, T) fp16/fp32 on this engine's GPU -> (B, 40, T)
@@ -611,6 +616,84 @@ class Stream:
                 source = _device_view(address, (engine.output_channels, self.rows), engine.device)
                 out.copy_(source[:, first.value:first.value + count.value])
         return out
+
+
+class LongStream:
+    """Streaming causal inference over ONE utterance longer than a window.
+
+    Reference Transformer.forward (ppgs/model/transformer.py:49-64) runs sequences of more than
+    500 frames as independent windows of 500 rows every 400 frames over the left-replicate-padded
+    sequence (row tt of window i = frame max(400 i + tt - 50, 0)), keeps rows [50, 450) of each and
+    concatenates them.  A LongStream feeds every frame to the one or two windows it belongs to --
+    each a KV-cached Stream -- and emits the kept rows in frame order: the causal forward of the
+    whole utterance as the reference computes it for T > 500, incrementally, with the windows'
+    own look-ahead of 4 frames.  (For T <= 500 the reference uses ONE unpadded window, which is
+    what Stream reproduces; the regime cannot be switched once frames have been emitted.)"""
+
+    def __init__(self, engine, dtype=torch.float16):
+        self.engine, self.dtype = engine, dtype
+        self.chunk, self.overlap = config.CHUNK_LENGTH, config.CHUNK_OVERLAP
+        self.stride = self.chunk - 2 * self.overlap
+        self.received = 0
+        self._windows = {}          # index -> [Stream, rows emitted so far]
+        self._first = None
+
+    def _window(self, index):
+        if index not in self._windows:
+            self._windows[index] = [Stream(self.engine, self.chunk, self.dtype), 0]
+        return self._windows[index]
+
+    def _emit(self, index, out, total=None):
+        """rows of window `index` that became final -> the kept ones (as frames, in order)"""
+        entry = self._windows[index]
+        first = entry[1]
+        entry[1] += out.shape[1]
+        rows = torch.arange(first, entry[1], device=out.device)
+        keep = (rows >= self.overlap) & (rows < self.chunk - self.overlap)
+        if total is not None:
+            keep &= (self.stride * index + rows - self.overlap) < total
+        return out[:, keep]
+
+    def push(self, chunk, flush=False, softmax=True):
+        """chunk (input_channels, n) -> (40, k): the posteriors of the k frames that became final."""
+        engine = self.engine
+        if chunk is None:
+            chunk = torch.empty(engine.input_channels, 0, dtype=self.dtype, device=engine.device)
+        chunk = chunk.to(device=engine.device, dtype=self.dtype)
+        n = chunk.shape[1]
+        if self._first is None and n:
+            self._first = chunk[:, :1]
+        pieces = []
+        lo, hi = self.received, self.received + n
+        if n:
+            first_window = max((lo + self.overlap - (self.chunk - 1) + self.stride - 1) // self.stride, 0)
+            last_window = (hi - 1 + self.overlap) // self.stride
+            for index in range(first_window, last_window + 1):
+                # window rows tt = f - stride * index + overlap in [0, chunk)
+                f0 = max(lo, self.stride * index - self.overlap)
+                f1 = min(hi, self.stride * index - self.overlap + self.chunk)
+                if f1 <= f0:
+                    continue
+                rows = chunk[:, f0 - lo:f1 - lo]
+                if index == 0 and f0 == 0:        # the replicate padding on the left of the first window
+                    rows = torch.cat([self._first.expand(-1, self.overlap), rows], dim=1)
+                stream = self._window(index)[0]
+                pieces.append(self._emit(index, stream.push(rows, softmax=softmax)))
+        self.received = hi
+        if flush:
+            total = self.received
+            for index in sorted(self._windows):
+                stream = self._windows[index][0]
+                if self.stride * index < total:   # a window whose kept rows start past the end does not exist
+                    pieces.append(self._emit(index, stream.push(None, flush=True, softmax=softmax), total))
+            self._windows.clear()
+        else:
+            # windows that have emitted all their kept rows are done
+            for index in [i for i, entry in self._windows.items() if entry[1] >= self.chunk - self.overlap]:
+                del self._windows[index]
+        if not pieces:
+            return torch.empty(engine.output_channels, 0, dtype=torch.float32, device=engine.device)
+        return torch.cat(pieces, dim=1)
 
 
 def _device_view(address, shape, device):

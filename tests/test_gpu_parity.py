@@ -921,6 +921,33 @@ def test_w2v2_body_shapes_vs_hf_modules():
             assert (out[item, :count] - ref[item, :count]).abs().max() < 1e-4, (shape, item)
 
 
+@pytest.mark.parametrize('total', [1130, 780, 501])
+def test_long_stream_equals_chunked_causal_forward(total):
+    """An utterance longer than a window, streamed (engine.long_stream: every frame goes to the one
+    or two 500-row windows of the reference's chunk rule it belongs to, each a KV-cached stream)
+    equals the reference's chunked causal forward (oracle), frame by frame.  1130 frames = three
+    windows; 780 = two, with a third that starts inside the utterance but past its kept range;
+    501 = the shortest chunked case."""
+    engine, state = eng(causal=True)
+    gen = torch.Generator().manual_seed(55)
+    feats = torch.randn(80, total, generator=gen).half()
+    ref = O.from_features(state, feats[None].float(), torch.tensor([total]), is_causal=True).numpy()[0]
+    stream = engine.long_stream()
+    pieces, received = [], 0
+    sizes = [16, 48, 7, 100, 1, 64, 33, 90, 2, 76, 130, 49]
+    index = 0
+    while received < total:
+        n = min(sizes[index % len(sizes)], total - received)
+        pieces.append(stream.push(feats[:, received:received + n].cuda()))
+        received += n
+        index += 1
+        assert sum(p.shape[1] for p in pieces) <= max(received - 4, 0)
+    pieces.append(stream.push(None, flush=True))
+    out = torch.cat(pieces, dim=1).cpu().numpy()
+    assert out.shape == (40, total)
+    assert np.abs(out - ref).max() < FP32_TOL
+
+
 @pytest.mark.parametrize('capacity,total,step', [(40, 40, 1), (17, 9, 2), (500, 500, 125), (64, 3, 3)])
 def test_kv_cached_stream_edges(capacity, total, step):
     """Streams at the edges: one-frame pushes, fewer frames than the convolutions' look-ahead before
