@@ -714,20 +714,70 @@ int frontend_for(int device, Frontend** out) {
         }
         std::vector<float> dense;
         mel_filterbank(&dense);
-        std::vector<int> start(80), count(80), offset(80);
-        std::vector<float> packed;
-        for (int m = 0; m < 80; ++m) {
-            int first = -1, last = -1;
-            for (int k = 0; k < 513; ++k)
-                if (dense[(size_t)m * 513 + k] != 0.f) { if (first < 0) first = k; last = k; }
-            start[m] = first < 0 ? 0 : first;
-            count[m] = first < 0 ? 0 : last - first + 1;
-            offset[m] = (int)packed.size();
-            for (int k = 0; k < count[m]; ++k) packed.push_back(dense[(size_t)m * 513 + start[m] + k]);
-            // rows padded with zero weights to a multiple of 8 bins (the kernel's unroll);
-            // start + count stays within the 520-float magnitude rows
-            while (count[m] % 8) { packed.push_back(0.f); ++count[m]; }
-            if (start[m] + count[m] > 520) return fail(PPG_EINVAL, "mel filter %d overruns the magnitude row", m);
+        // Banded filterbank image (ppg_launch.h, FrontendTables): per block of 16 filters the 32-bin
+        // steps from the block's first non-zero bin (rounded down to 32) to its last.
+        struct Block { int index, first, steps; };
+        std::vector<Block> blocks;
+        for (int mb = 0; mb < 5; ++mb) {
+            int first = 513, last = -1;
+            for (int m = 16 * mb; m < 16 * mb + 16; ++m)
+                for (int k = 0; k < 513; ++k)
+                    if (dense[(size_t)m * 513 + k] != 0.f) { first = std::min(first, k); last = std::max(last, k); }
+            if (last < 0) { first = 0; last = 0; }
+            first &= ~31;
+            blocks.push_back({mb, first, (last - first) / 32 + 1});
+        }
+        // A wave runs kMelSteps steps in two segments (kMelSegment + the rest) and can finish a block only at
+        // the end of a segment: longest block first, a block longer than the first segment takes a whole
+        // wave, the others the smallest free segment they fit (of the wave with the fewest steps so far).
+        std::stable_sort(blocks.begin(), blocks.end(), [](const Block& a, const Block& b) { return a.steps > b.steps; });
+        std::vector<uint16_t> img;
+        auto half_bits = [](float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; };
+        auto half_value = [](uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
+        auto add_fragments = [&](int mb, int first) {          // -> index of the high fragment
+            const int frag = (int)(img.size() / 512);
+            img.resize(img.size() + 1024, 0);
+            for (int lane = 0; lane < 64 && mb >= 0; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = 16 * mb + (lane & 15), k = first + 8 * (lane >> 4) + j;
+                    const float w = k < 513 ? dense[(size_t)m * 513 + k] * 65536.0f : 0.f;
+                    const uint16_t hi = half_bits(w);
+                    img[(size_t)frag * 512 + lane * 8 + j] = hi;
+                    img[(size_t)(frag + 1) * 512 + lane * 8 + j] = half_bits(w - half_value(hi));
+                }
+            return frag;
+        };
+        const int zero_frag = add_fragments(-1, 0);
+        const int NS = ppg::kMelSteps, seg_first[2] = {0, ppg::kMelSegment}, seg_size[2] = {ppg::kMelSegment, NS - ppg::kMelSegment};
+        std::vector<int> prog(4 * NS * 4, 0);
+        for (int i = 0; i < 4 * NS; ++i) { prog[i * 4] = zero_frag; prog[i * 4 + 2] = -1; }
+        int used[4] = {0, 0, 0, 0};
+        bool taken[4][2] = {};
+        for (const Block& blk : blocks) {
+            int wave = -1, seg = -1;
+            for (int w = 0; w < 4; ++w) {
+                if (blk.steps > seg_size[0]) {               // whole wave
+                    if (!taken[w][0] && !taken[w][1] && blk.steps <= NS && wave < 0) { wave = w; seg = 2; }
+                    continue;
+                }
+                for (int g = 0; g < 2; ++g) {
+                    if (taken[w][g] || blk.steps > seg_size[g]) continue;
+                    const bool better = wave < 0 || used[w] < used[wave] || (used[w] == used[wave] && w == wave && seg_size[g] < seg_size[seg]);
+                    if (better) { wave = w; seg = g; }
+                }
+            }
+            if (wave < 0 || blk.first + 32 * blk.steps > 544)
+                return fail(PPG_EINVAL, "mel filter block %d: %d steps from bin %d do not fit the frontend's program", blk.index, blk.steps, blk.first);
+            // the block's steps END at its segment's end (the steps before them stay zero fragments)
+            const int last = seg == 2 ? NS - 1 : seg_first[seg] + seg_size[seg] - 1;
+            for (int st = 0; st < blk.steps; ++st) {
+                int* e = &prog[(wave * NS + last - (blk.steps - 1) + st) * 4];
+                e[0] = add_fragments(blk.index, blk.first + 32 * st);
+                e[1] = (blk.first + 32 * st) * 2;
+            }
+            prog[(wave * NS + last) * 4 + 2] = blk.index;
+            if (seg == 2) taken[wave][0] = taken[wave][1] = true; else taken[wave][seg] = true;
+            used[wave] += blk.steps;
         }
         auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
             void* p = nullptr;
@@ -740,17 +790,8 @@ int frontend_for(int device, Frontend** out) {
         int rc;
         if ((rc = up(hann.data(), hann.size() * 4, (const void**)&f.tb.hann))) return rc;
         if ((rc = up(tw.data(), tw.size() * 8, (const void**)&f.tb.twiddle))) return rc;
-        if ((rc = up(start.data(), 320, (const void**)&f.tb.mel_start))) return rc;
-        if ((rc = up(count.data(), 320, (const void**)&f.tb.mel_count))) return rc;
-        if ((rc = up(offset.data(), 320, (const void**)&f.tb.mel_offset))) return rc;
-        if ((rc = up(packed.data(), packed.size() * 4, (const void**)&f.tb.mel_weight))) return rc;
-        if ((int)packed.size() > ppg::kMaxMelWeights) return fail(PPG_EINVAL, "mel filterbank: %zu packed weights", packed.size());
-        f.tb.mel_weights = (int)packed.size();
-        // filters, longest first
-        std::vector<int> order(80);
-        for (int m = 0; m < 80; ++m) order[m] = m;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count[a] > count[b]; });
-        if ((rc = up(order.data(), order.size() * 4, (const void**)&f.tb.mel_task))) return rc;
+        if ((rc = up(img.data(), img.size() * 2, (const void**)&f.tb.mel_img))) return rc;
+        if ((rc = up(prog.data(), prog.size() * 4, (const void**)&f.tb.mel_prog))) return rc;
         f.tb.dbg = nullptr;
         if (getenv("PPGS_AMD_FE_TIMING")) {
             std::vector<unsigned long long> zeros(64, 0);

@@ -34,7 +34,9 @@ hipError_t launch_w2v2_layernorm(int precision, int H, const float* in32, const 
                                  long rows, int T_in, int R_out, float eps, float* out32, char* out16, hipStream_t s);
 hipError_t launch_w2v2_output(int precision, const char* rows, int batch, int rows_per_item, long frames, float* out, hipStream_t s);
 
-constexpr int kMaxMelWeights = 1536;   // LDS room for the packed filterbank (1001 non-zeros + interior zeros)
+constexpr int kFrontendFrames = 16;    // frames per frontend group (the filterbank MFMA's 16 columns)
+constexpr int kMelSteps = 8;           // banded filterbank: 32-bin steps per wave of the frontend ...
+constexpr int kMelSegment = 5;         // ... in two segments of 5 + 3: a filter block fills one segment or a whole wave
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and not a stream
 // operation (it must stay out of graph capture): done once per (kernel
@@ -54,13 +56,14 @@ struct LdsLimit {
 struct FrontendTables {
     const float* hann;        // [1024]
     const float2* twiddle;    // [1024] exp(-2 pi i j / 1024)
-    const int* mel_start;     // [80] first bin of each filter
-    const int* mel_count;     // [80]
-    const int* mel_offset;    // [80] offset into mel_weight
-    const float* mel_weight;  // packed non-zeros
-    int mel_weights;          // entries of mel_weight (<= kMaxMelWeights)
+    // Banded filterbank for v_mfma_f32_16x16x32_f16: A fragments of 16 filters x 32 bins, lane l holds
+    // filter 16 block + (l & 15), bins first + 8 (l >> 4) ..+7 as fp16; fragment 2 i is the high part of
+    // weight * 2^16, 2 i + 1 the low part.  mel_prog[wave][kMelSteps] = (high fragment, byte offset of the
+    // step's first bin in a magnitude row, filter block the step completes or -1, 0); a block completes at
+    // step kMelSegment - 1 or at the last step; unused steps point at a zero fragment pair.
+    const void* mel_img;
+    const int4* mel_prog;
     unsigned long long* dbg;  // PPG_FE_TIMING builds: s_memtime stamps of workgroup 0 (PPGS_AMD_FE_TIMING=1)
-    const int* mel_task;      // [80] filters, longest first: lane l of a pair's wave takes entries l and 127 - l
 };
 
 hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int batch, int samples,
