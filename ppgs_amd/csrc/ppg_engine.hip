@@ -947,8 +947,15 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         if ((rc = upload_f32(E, wts->output_bias, cfg->output_channels, 48, &e->b_out))) return rc;
     }
     e->layers.resize(L);
+    // The attention kernel takes its Q rows already multiplied by log2(e) / sqrt(head_dim) (attn_body's softmax
+    // is a bare exp2 of the score accumulator): the factor goes into the Q rows of W_qkv and b_qkv here, before
+    // the weights are rounded to the operand type.
+    const float qscale = (float)(1.4426950408889634 / sqrt((double)dh));
+    std::vector<float> in_w((size_t)3 * H * H), in_b((size_t)3 * H);
     for (int l = 0; l < L; ++l) {
         DevLayer& d = e->layers[l];
+        for (size_t i = 0; i < in_w.size(); ++i) in_w[i] = wts->in_proj_weight[l][i] * (i < (size_t)H * H ? qscale : 1.0f);
+        for (int i = 0; i < 3 * H; ++i) in_b[i] = wts->in_proj_bias[l][i] * (i < H ? qscale : 1.0f);
         auto plain = [&](const float* w, int rows, int cols, char** dst) {
             return upload_matrix(E, rows, cols, rows, cols, [&](int r, int c) { return w[(size_t)r * cols + c]; }, dst);
         };
@@ -956,13 +963,13 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         auto paired = [&](const float* w, int rows, int cols, char** dst) {
             return upload_matrix(E, rows, cols, rows, cols, [&](int r, int c) { return w[(size_t)pair_row(r) * cols + c]; }, dst);
         };
-        if ((rc = paired(wts->in_proj_weight[l], 3 * H, H, &d.wqkv))) return rc;
+        if ((rc = paired(in_w.data(), 3 * H, H, &d.wqkv))) return rc;
         if ((rc = paired(wts->out_proj_weight[l], H, H, &d.wo))) return rc;
         if ((rc = plain(wts->linear1_weight[l], F, H, &d.w1))) return rc;
         if ((rc = paired(wts->linear2_weight[l], H, F, &d.w2))) return rc;
         d.wqkvk = d.wqkv;
         if (e->sz == 4) {
-            const float* w = wts->in_proj_weight[l];
+            const float* w = in_w.data();
             rc = upload_matrix(E, 3 * H, H, 3 * H, H, [&](int r, int c) { return w[(size_t)pair_row(r) * H + pair_row(c)]; }, &d.wqkvk);
             if (rc) return rc;
         }
@@ -1023,7 +1030,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
             // W_qkv of THIS layer (the previous layer's kernel runs it as its tail): per wave 3 RB steps of
             // 32 rows: Q rows 32 RB w + 32 rb + phi, K likewise, V rows in attn_kernel's tile order
             // (V^T row r = natural feature pair_row(r)); K order = the x2 panel's (as W1)
-            const float* wq = wts->in_proj_weight[l];
+            const float* wq = in_w.data();
             rc = image(4 * 3 * RB * KS, [&](int f, int ln, int j) {      // [w][step][ks]
                 const int ks = f % KS, st = (f / KS) % (3 * RB), w = f / (KS * 3 * RB);
                 const int rb = st % RB, kind = st / RB;
@@ -1033,7 +1040,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
             }, &d.wq_img);
             if (rc) return rc;
         }
-        if ((rc = upload_f32(E, wts->in_proj_bias[l], 3 * H, 0, &d.bqkv))) return rc;
+        if ((rc = upload_f32(E, in_b.data(), 3 * H, 0, &d.bqkv))) return rc;
         if ((rc = upload_f32(E, wts->out_proj_bias[l], H, 0, &d.bo))) return rc;
         if ((rc = upload_f32(E, wts->linear1_bias[l], F, 0, &d.b1))) return rc;
         if ((rc = upload_f32(E, wts->linear2_bias[l], H, 0, &d.b2))) return rc;
@@ -1222,7 +1229,6 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             AttnArgs a{};
             a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
             a.ao = ao; a.H = H; a.causal = c.is_causal;
-            a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
             a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32; a.heads = c.heads;
             a.dbg = l == 0 ? e->attn_dbg : nullptr;
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
@@ -1528,7 +1534,6 @@ int ppg_stream_push(PpgStream* st, const void* chunk, int n, int flush, int soft
                 AttnArgs a{};
                 a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
                 a.ao = ao; a.H = H; a.causal = 1;
-                a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)e->head_dim));
                 a.items = st->d_items; a.win = st->d_win; a.M = R; a.ao_tiled = 0; a.heads = c.heads;
                 LAUNCH_OK(ppg::launch_attn(prec, a, nitems, c.heads, e->head_dim, s), "stream attention");
             }
@@ -1785,6 +1790,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     for (int l = 0; l < L; ++l) {
         const PpgW2v2LayerWeights& lw = w->layers[l];
         PpgW2v2Body::Layer& d = m->layer[l];
+        const float qscale = (float)(1.4426950408889634 / sqrt(64.0));      // 12 heads of 64
         NEED(lw.q_weight); NEED(lw.q_bias); NEED(lw.k_weight); NEED(lw.k_bias); NEED(lw.v_weight); NEED(lw.v_bias);
         NEED(lw.out_weight); NEED(lw.out_bias); NEED(lw.norm1_weight); NEED(lw.norm1_bias);
         NEED(lw.ffn1_weight); NEED(lw.ffn1_bias); NEED(lw.ffn2_weight); NEED(lw.ffn2_bias); NEED(lw.norm2_weight); NEED(lw.norm2_bias);
@@ -1793,11 +1799,11 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
                            [&](int r, int c) {
                                const int rr = pair_row(r), which = rr / H, row = rr - which * H;
                                const float* src = which == 0 ? lw.q_weight : (which == 1 ? lw.k_weight : lw.v_weight);
-                               return src[(size_t)row * H + c];
+                               return src[(size_t)row * H + c] * (which == 0 ? qscale : 1.0f);    // (see ppg_engine_create)
                            }, &d.wqkv);
         if (rc) return rc;
         std::vector<float> bq(3 * (size_t)H);
-        memcpy(bq.data(), lw.q_bias, H * sizeof(float));
+        for (int i = 0; i < H; ++i) bq[i] = lw.q_bias[i] * qscale;
         memcpy(bq.data() + H, lw.k_bias, H * sizeof(float));
         memcpy(bq.data() + 2 * H, lw.v_bias, H * sizeof(float));
         if ((rc = upload_f32(E, bq.data(), 3 * (size_t)H, 0, &d.bqkv))) return rc;
@@ -1968,7 +1974,6 @@ int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* 
             AttnArgs a{};
             a.qk = qk; a.qk_ld_bytes = 2 * H * sz; a.vt = vt; a.vt_ld_bytes = vt_ld * sz;
             a.ao = ao; a.H = H; a.causal = 0;
-            a.scale_log2e = (float)(1.4426950408889634 / sqrt(64.0));
             a.items = d_items; a.win = d_win; a.M = M; a.ao_tiled = 0; a.heads = m->heads;
             LAUNCH_OK(ppg::launch_attn(prec, a, ni, m->heads, 64, s), "w2v2 attention");
         }

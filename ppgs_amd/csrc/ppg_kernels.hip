@@ -3,6 +3,9 @@
 // See ppg_device.h for the operand orientation shared by all of them.
 #include "ppg_device.h"
 #include "ppg_launch.h"
+
+#include <stdlib.h>
+#include <string.h>
 #include "ppg_lds.h"
 
 #include <limits.h>
@@ -1358,13 +1361,23 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) oacc[db][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrun[NTQ], lrun[NTQ];
+    // Softmax with a per-query SHIFT instead of a running maximum.  The Q rows arrive scaled by
+    // log2(e) / sqrt(d) (folded into W_q and b_q by the engine), the score accumulators start at -shift
+    // (the MFMA's C operand), so a score comes out of the matrix pipe as s - shift and p = exp2(that) is
+    // ONE v_exp_f32: no multiply-subtract, no row maximum, no rescale of O in the tile loop.  The shift
+    // is the exact maximum of the query's first tile; softmax needs nothing more of it than that no p
+    // overflows (the result O / l does not depend on it, and p's relative precision does not either):
+    // a later tile whose p exceeds P::kProbCeil (2^40 in bf16 / fp32, 2^10 in fp16) re-bases the shift
+    // to the new maximum -- rescales l and O, redoes that tile's p -- which trained attention logits
+    // do not do after the first tile (covered by tests/test_gpu_parity.py::test_attention_rebase).
+    float shift[NTQ], lrun[NTQ];
+    f32x4 cinit[NTQ];                           // {-shift x 4}: C operand of a tile's first MFMAs
 #pragma unroll
-    for (int t = 0; t < NTQ; ++t) { mrun[t] = -INFINITY; lrun[t] = 0.f; }
+    for (int t = 0; t < NTQ; ++t) { shift[t] = 0.f; lrun[t] = 0.f; cinit[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const uint32_t lds0 = lds_addr(smem);
     constexpr int NSTEP = DG * KB;              // fragments of a K tile (16 KiB / 1 KiB)
-    // S^T = K q^T of tile kt into s (fragment i = (kg, kb) = (i / KB, i % KB));
+    // S^T = K q^T - shift of tile kt into s (fragment i = (kg, kb) = (i / KB, i % KB));
     // `filler(step)` is VALU work issued between the MFMAs
     auto scores = [&](int kt, f32x4 (&s)[KB][NTQ], auto filler) {
         using LK = FragLayout<ROWK, KB>;
@@ -1374,81 +1387,96 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int t = 0; t < NTQ; ++t) {
-                if constexpr (i / KB == 0) P::mma0(s[i % KB][t], kf, qf[0][t]);
+                if constexpr (i / KB == 0) P::mmac(s[i % KB][t], kf, qf[0][t], cinit[t]);
                 else P::mma(s[i % KB][t], kf, qf[i / KB][t]);
             }
             filler(ic);
         });
     };
 
-    // Online softmax of one tile in the exp2 domain: p = exp2(s*c - m*c),
-    // c = log2(e)/sqrt(d), one FMA + one v_exp_f32 per score; the running max
-    // is tracked on the raw scores (c > 0).  Masking code only runs for tiles
-    // that reach past the valid keys / the causal diagonal; O is rescaled only
-    // when a max moved.  Cut into NPIECE pieces so that it can be issued between
-    // the MFMAs of the next tile's scores: per query block t
-    //   piece 0: mask, row max (lane partial + shuffles over the 4 lane groups)
-    //   piece 1: rescale of the running sum and of O
-    //   piece 2 + kb: exponentials of key block kb, packed as the PV B fragment
     // keys below key_limit[t] + 4 g count for the lane's query of block t (padding mask, causal diagonal)
     int key_limit[NTQ];
 #pragma unroll
     for (int t = 0; t < NTQ; ++t)
         key_limit[t] = (a.causal ? min(w.valid, qw0 + 16 * t + idx + 1) : w.valid) - 4 * g;
-    constexpr int PPT = 2 + KB;
+    // the lane's keys of tile kt are 16 kb + e + (kt KT + 4 g): one subtraction, then constants against it
+    // (written out per key, the compiler hoists the 16 key indices above the branch and every tile pays)
+    auto mask_tile = [&](int t, int kt, f32x4 (&s)[KB][NTQ]) {
+        const int rel = key_limit[t] - kt * KT;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kb * 16 + e >= rel) s[kb][t][e] = -INFINITY;
+    };
+    auto tile_max = [&](int t, f32x4 (&s)[KB][NTQ]) {
+        float mx = max3(s[0][t][0], s[0][t][1], s[0][t][2]);
+        mx = fmaxf(mx, s[0][t][3]);
+#pragma unroll
+        for (int kb = 1; kb < KB; ++kb) {
+            mx = max3(mx, s[kb][t][0], s[kb][t][1]);
+            mx = max3(mx, s[kb][t][2], s[kb][t][3]);
+        }
+        return wave_max_g(mx);                  // over the 4 lane groups: all keys of the tile
+    };
+    // p of key block kb: exponentials, their sum, the PV B fragment, and the largest p seen (as bits:
+    // p >= 0, so the 16-bit patterns order like the values)
+    float psum[NTQ];
+    uint32_t ptop[NTQ];
+    float ptopf[NTQ];
+    auto exp_block = [&](auto moved, int t, int kb, float d, f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
+        constexpr bool MOVED = decltype(moved)::value;      // re-basing: the scores are d above the new shift
+        const float p0 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][0] - d : s[kb][t][0]);
+        const float p1 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][1] - d : s[kb][t][1]);
+        const float p2 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][2] - d : s[kb][t][2]);
+        const float p3 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][3] - d : s[kb][t][3]);
+        psum[t] += (p0 + p1) + (p2 + p3);
+        if constexpr (P::kIsBF16) {
+            const uint32_t lo = P::pack2(p0, p1), hi = P::pack2(p2, p3);
+            if (kb & 1) { pf[kb >> 1][t].z = lo; pf[kb >> 1][t].w = hi; }
+            else        { pf[kb >> 1][t].x = lo; pf[kb >> 1][t].y = hi; }
+            ptop[t] = pk_max_u16(pk_max_u16(ptop[t], lo), hi);
+        } else {
+            pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
+            ptopf[t] = max3(ptopf[t], fmaxf(p0, p1), fmaxf(p2, p3));
+        }
+    };
+    // Softmax of tile kt in NPIECE pieces, issued between the MFMAs of the next tile's scores:
+    // per query block t, piece 0 masks (tiles that reach past the valid keys / the causal diagonal only),
+    // piece 1 + kb exponentiates key block kb
+    constexpr int PPT = 1 + KB;
     constexpr int NPIECE = NTQ * PPT;
-    const float c = a.scale_log2e;
-    float mnew[NTQ], mc[NTQ], psum[NTQ];
     auto softmax_piece = [&](auto jc, int kt, bool need_mask, f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
         constexpr int j = decltype(jc)::value;
         constexpr int t = j / PPT, r = j % PPT;
         if constexpr (r == 0) {
-            if (need_mask) {
-                // the lane's keys of the tile are 16 kb + e + (kt KT + 4 g): one subtraction, then constants
-                // against it (written out per key, the compiler hoists the 16 key indices above this branch
-                // and every tile pays for them)
-                const int rel = key_limit[t] - kt * KT;
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (kb * 16 + e >= rel) s[kb][t][e] = -INFINITY;
-            }
-            float mx = max3(s[0][t][0], s[0][t][1], s[0][t][2]);
-            mx = max3(mx, s[0][t][3], mrun[t]);
-#pragma unroll
-            for (int kb = 1; kb < KB; ++kb) {
-                mx = max3(mx, s[kb][t][0], s[kb][t][1]);
-                mx = max3(mx, s[kb][t][2], s[kb][t][3]);
-            }
-            mnew[t] = wave_max_g(mx);           // includes the running max (equal in the 4 lane groups)
-            mc[t] = (mnew[t] == -INFINITY) ? 0.f : mnew[t] * c;       // fully masked so far: p = exp2(-inf) = 0
-        } else if constexpr (r == 1) {
-            if (__any(mnew[t] != mrun[t])) {
-                const float alpha = __builtin_amdgcn_exp2f(mrun[t] * c - mc[t]);   // first tile: exp2(-inf) = 0
-                lrun[t] *= alpha;
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
-                    oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
-                }
-                mrun[t] = mnew[t];
-            }
-            psum[t] = 0.f;
+            if (need_mask) mask_tile(t, kt, s);
+            psum[t] = 0.f; ptop[t] = 0u; ptopf[t] = 0.f;
         } else {
-            constexpr int kb = r - 2;
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][0], c, -mc[t]));
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][1], c, -mc[t]));
-            const float p2 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][2], c, -mc[t]));
-            const float p3 = __builtin_amdgcn_exp2f(fmaf(s[kb][t][3], c, -mc[t]));
-            psum[t] += (p0 + p1) + (p2 + p3);
-            if constexpr (P::kIsBF16) {
-                if constexpr (kb & 1) { pf[kb >> 1][t].z = P::pack2(p0, p1); pf[kb >> 1][t].w = P::pack2(p2, p3); }
-                else                  { pf[kb >> 1][t].x = P::pack2(p0, p1); pf[kb >> 1][t].y = P::pack2(p2, p3); }
-            } else {
-                pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
+            exp_block(std::false_type{}, t, r - 1, 0.f, s, pf);
+        }
+    };
+    // some p of the tile is past the ceiling: move the shift to the tile's maximum
+    auto rebase = [&](f32x4 (&s)[KB][NTQ], f32x4 (&nxt)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const float d = fmaxf(tile_max(t, s), 0.f);       // (a fully masked tile: -inf -> 0)
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            lrun[t] *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
+                oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
             }
-            if constexpr (kb == KB - 1) lrun[t] += psum[t];
+            psum[t] = 0.f; ptop[t] = 0u; ptopf[t] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                exp_block(std::true_type{}, t, kb, d, s, pf);
+                // the next tile's scores were started from the old shift
+                nxt[kb][t][0] -= d; nxt[kb][t][1] -= d; nxt[kb][t][2] -= d; nxt[kb][t][3] -= d;
+            }
+            shift[t] += d;
+            cinit[t] = f32x4{-shift[t], -shift[t], -shift[t], -shift[t]};
         }
     };
 
@@ -1457,7 +1485,23 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     dma_wait_barrier();
 
     f32x4 scur[KB][NTQ], snext[KB][NTQ];
-    if (ntiles > 0) scores(0, scur, [](auto) {});
+    if (ntiles > 0) {
+        scores(0, scur, [](auto) {});
+        // the shift: the first tile's exact maximum per query (0 for a query without a valid key in it)
+        const bool mask0 = KT > w.valid || (a.causal && KT > qw0);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            if (mask0) mask_tile(t, 0, scur);
+            const float m0 = tile_max(t, scur);
+            shift[t] = (m0 == -INFINITY) ? 0.f : m0;
+            cinit[t] = f32x4{-shift[t], -shift[t], -shift[t], -shift[t]};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                scur[kb][t][0] -= shift[t]; scur[kb][t][1] -= shift[t];
+                scur[kb][t][2] -= shift[t]; scur[kb][t][3] -= shift[t];
+            }
+        }
+    }
     __syncthreads();                       // K buffer 0 is re-filled by iteration 0's DMA
 
 #ifdef PPG_ATTN_TIMING
@@ -1490,6 +1534,20 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
                 (softmax_piece(std::integral_constant<int, J>{}, kt, need_mask, scur, pf), ...);
             }(std::make_integer_sequence<int, NPIECE>{});
         }
+        // a p past the ceiling (wave-uniform test; the branch is cold)
+        bool high = false;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            if constexpr (P::kIsBF16) {
+                const uint32_t ceil = a.rebase_always ? P::kProbOne : P::kProbCeil;
+                high |= (ptop[t] & 0xffffu) > ceil || (ptop[t] >> 16) > ceil;
+            } else {
+                high |= ptopf[t] > (a.rebase_always ? 1.0f : 1.0e12f);
+            }
+        }
+        if (__any(high)) rebase(scur, snext, pf);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) lrun[t] += psum[t];
         stamp(kt, 2);
         using LV = FragLayout<ROWV, DB>;
         uint32_t fbv[LV::VAR];
@@ -1726,7 +1784,12 @@ hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s) {
 #endif
 }
 
-hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s) {
+hipError_t launch_attn(int precision, const AttnArgs& args, int nitems, int heads, int head_dim, hipStream_t s) {
+    // PPGS_AMD_ATTN_REBASE=always (read per launch: the tests switch it): the classic online softmax's worth of
+    // re-basing, to exercise the path trained logits never take
+    AttnArgs a = args;
+    const char* mode = getenv("PPGS_AMD_ATTN_REBASE");
+    a.rebase_always = (mode && strcmp(mode, "always") == 0) ? 1 : 0;
     if (precision == PPG_PRECISION_BF16) return launch_attn_p<PrecBF16>(a, nitems, heads, head_dim, s);
 #if PPG_OTHER_PRECISIONS
     if (precision == PPG_PRECISION_FP16) return launch_attn_p<PrecF16>(a, nitems, heads, head_dim, s);

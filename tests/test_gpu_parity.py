@@ -95,7 +95,7 @@ def test_frontend_silence_and_short(golden):
 
 
 def test_frontend_odd_frames_vs_oracle():
-    # frame count not a multiple of the 8-frame tile / of the frame pair
+    # frame count not a multiple of the 16-frame group / of the frame pair
     gen = torch.Generator().manual_seed(5)
     audio = 0.1 * torch.randn(3, 1, 160 * 37 + 59, generator=gen)
     ref = O.mel_from_audios(audio).numpy()
@@ -103,6 +103,30 @@ def test_frontend_odd_frames_vs_oracle():
     assert mel.shape == ref.shape == (3, 80, 37)
     d = ulp_diff(mel, ref)
     assert d.max() <= 1 and (d == 0).mean() >= 0.995
+
+
+def test_frontend_sample_staging_paths_vs_oracle():
+    """The kernel stages a group's samples by DMA: 16 bytes per lane for groups inside their
+    row when the rows are 16-byte aligned, 4 bytes per lane with one address per sample at the
+    reflect-padded row ends and for unaligned rows.  Long rows (interior groups exist) in all
+    three situations against the oracle."""
+    gen = torch.Generator().manual_seed(6)
+    frames = 16 * 9 + 5
+    for extra in (0, 2):                       # row length a multiple of 4 samples or not
+        audio = 0.1 * torch.randn(3, 1, 160 * frames + extra, generator=gen)
+        ref = O.mel_from_audios(audio).numpy()
+        mel = ppgs_amd.preprocess.mel.from_audios(audio.cuda()).cpu().numpy()
+        assert mel.shape == ref.shape == (3, 80, frames)
+        d = ulp_diff(mel, ref)
+        assert d.max() <= 1 and (d == 0).mean() >= 0.995
+        if extra == 0:
+            # the same rows from a buffer that starts 4 bytes past a 16-byte boundary
+            buf = torch.empty(audio.numel() + 1, device='cuda')
+            view = buf[1:].view_as(audio)
+            view.copy_(audio)
+            assert view.data_ptr() % 16 == 4
+            shifted = ppgs_amd.preprocess.mel.from_audios(view).cpu().numpy()
+            assert np.array_equal(shifted, mel)
 
 
 @pytest.mark.parametrize('rate', [48000, 44100, 22050, 8000, 16001])
@@ -302,6 +326,49 @@ def test_attention_tiles_of_two_widths(monkeypatch, precision, causal):
     assert np.isfinite(a).all() and np.abs(a - b).max() < tol
     ref = O.from_features(state, feats, lengths, is_causal=causal).numpy()
     assert np.abs(a - ref).max() < tol
+
+
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16', 'bf16'])
+def test_attention_rebase(monkeypatch, precision, causal):
+    """The attention kernel keeps a per-query softmax shift (the first key tile's maximum) and
+    re-bases it only when a probability passes 2^40 (2^10 with fp16 operands) -- which the seeded
+    weights never reach.  PPGS_AMD_ATTN_REBASE=always lowers that ceiling to 1: every tile with a
+    new maximum re-bases (rescale of l and O, the tile's p redone, the next tile's scores, already
+    started from the old shift, corrected).  Same posteriors as the oracle either way.  Then, at the
+    real ceiling, Q/K weights scaled so that the logits span hundreds: tiles past the first DO
+    overflow the ceiling there."""
+    lengths = [500, 333, 64, 17]
+    gen = torch.Generator().manual_seed(77)
+    feats = torch.randn(len(lengths), 80, 500, generator=gen).half()
+    state = W.seeded_state_dict(seed=1234)
+    engine = E.Engine(state, 0, precision, causal)
+    ref = O.from_features(state, feats, lengths, is_causal=causal).numpy()
+    tol = TOL[precision]
+    lazy = run(engine, feats, lengths)
+    monkeypatch.setenv('PPGS_AMD_ATTN_REBASE', 'always')
+    eager = run(engine, feats, lengths)
+    monkeypatch.delenv('PPGS_AMD_ATTN_REBASE')
+    assert np.abs(lazy - ref).max() < tol and np.abs(eager - ref).max() < tol
+    if precision == 'fp32':
+        hot = {k: v.clone() for k, v in state.items()}
+        for name in hot:
+            if name.endswith('self_attn.in_proj_weight'):
+                hot[name][:512] *= 12.0              # q and k rows: logits x 144
+        ref = O.from_features(hot, feats, lengths, is_causal=causal).numpy()
+        hot_engine = E.Engine(hot, 0, precision, causal)
+        lazy = run(hot_engine, feats, lengths)
+        monkeypatch.setenv('PPGS_AMD_ATTN_REBASE', 'always')
+        eager = run(hot_engine, feats, lengths)
+        monkeypatch.delenv('PPGS_AMD_ATTN_REBASE')
+        # near one-hot attention over logits of magnitude 10^2..10^3: an fp32 score accumulator that starts
+        # at -shift rounds differently for different shifts (3e-5 absolute on such a logit, i.e. 2e-5
+        # relative on p), and five layers of near-argmax attention amplify that
+        assert np.isfinite(lazy).all() and np.abs(lazy - eager).max() < 2e-3, np.abs(lazy - eager).max()
+        # against the oracle only in distribution: with logits this large two keys tie to within fp32 rounding
+        # in a few of the 20 000 softmaxes, and which one wins differs between any two implementations
+        err = np.abs(lazy - ref)
+        assert err.mean() < 1e-4 and np.quantile(err, 0.995) < 2e-3, (err.mean(), np.quantile(err, 0.995), err.max())
 
 
 def test_unfused_ffn_path_agrees(monkeypatch):
