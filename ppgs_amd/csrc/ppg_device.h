@@ -72,8 +72,7 @@ struct PrecBF16 {
     static constexpr int kBytes = 2;
     static constexpr int KG = 32;   // elements per 64-byte K-group
     static constexpr bool kIsBF16 = true;
-    static constexpr uint32_t kProbCeil = 0x5380;   // bf16 2^40: attention re-bases its softmax shift above this (attn_body)
-    static constexpr uint32_t kProbOne = 0x3f80;
+    static constexpr float kProbCeil = 1.0995116e12f;   // 2^40: attention re-bases its softmax shift above this (attn_body)
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
     static __device__ __forceinline__ uint16_t cvt1(float v) { return f32_to_bf16_rne(v); }
     static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -104,8 +103,7 @@ struct PrecF16 {
     static constexpr int kBytes = 2;
     static constexpr int KG = 32;
     static constexpr bool kIsBF16 = true;
-    static constexpr uint32_t kProbCeil = 0x6400;   // fp16 2^10 (the format ends at 2^16)
-    static constexpr uint32_t kProbOne = 0x3c00;
+    static constexpr float kProbCeil = 1024.0f;         // 2^10 (fp16 ends at 2^16)
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
     static __device__ __forceinline__ uint16_t cvt1(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
     static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -131,6 +129,7 @@ struct PrecF32 {
     static constexpr int kBytes = 4;
     static constexpr int KG = 16;
     static constexpr bool kIsBF16 = false;
+    static constexpr float kProbCeil = 1.0995116e12f;
     static __device__ __forceinline__ uint32_t pack2(float, float) { return 0u; }   // never used: 32-bit layouts
     static __device__ __forceinline__ float cvt1(float v) { return v; }
     static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -207,11 +206,6 @@ __device__ __forceinline__ float wave_sum_g(float v) {
 }
 // max of three without the NaN-canonicalising copies fmaxf() drags in for
 // values the compiler cannot prove canonical (MFMA results)
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-// per-half unsigned maximum of two packed 16-bit pairs (v_pk_max_u16)
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
 __device__ __forceinline__ float max3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     // ONE v_exp_f32: no multiply-subtract, no row maximum, no rescale of O in the tile loop.  The shift
     // is the exact maximum of the query's first tile; softmax needs nothing more of it than that no p
     // overflows (the result O / l does not depend on it, and p's relative precision does not either):
-    // a later tile whose p exceeds P::kProbCeil (2^40 in bf16 / fp32, 2^10 in fp16) re-bases the shift
+    // a later tile where a lane's p sum exceeds P::kProbCeil (2^40 in bf16 / fp32, 2^10 in fp16) re-bases the shift
     // to the new maximum -- rescales l and O, redoes that tile's p -- which trained attention logits
     // do not do after the first tile (covered by tests/test_gpu_parity.py::test_attention_rebase).
     float shift[NTQ], lrun[NTQ];
@@ -1419,11 +1419,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         }
         return wave_max_g(mx);                  // over the 4 lane groups: all keys of the tile
     };
-    // p of key block kb: exponentials, their sum, the PV B fragment, and the largest p seen (as bits:
-    // p >= 0, so the 16-bit patterns order like the values)
+    // p of key block kb: exponentials, their sum (which is also what the ceiling is tested on: a lane's 4 KB
+    // values of a tile are all below their sum), the PV B fragment
     float psum[NTQ];
-    uint32_t ptop[NTQ];
-    float ptopf[NTQ];
     auto exp_block = [&](auto moved, int t, int kb, float d, f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
         constexpr bool MOVED = decltype(moved)::value;      // re-basing: the scores are d above the new shift
         const float p0 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][0] - d : s[kb][t][0]);
@@ -1435,10 +1433,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             const uint32_t lo = P::pack2(p0, p1), hi = P::pack2(p2, p3);
             if (kb & 1) { pf[kb >> 1][t].z = lo; pf[kb >> 1][t].w = hi; }
             else        { pf[kb >> 1][t].x = lo; pf[kb >> 1][t].y = hi; }
-            ptop[t] = pk_max_u16(pk_max_u16(ptop[t], lo), hi);
         } else {
             pf[kb][t] = u32x4{__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3)};
-            ptopf[t] = max3(ptopf[t], fmaxf(p0, p1), fmaxf(p2, p3));
         }
     };
     // Softmax of tile kt in NPIECE pieces, issued between the MFMAs of the next tile's scores:
@@ -1451,7 +1447,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         constexpr int t = j / PPT, r = j % PPT;
         if constexpr (r == 0) {
             if (need_mask) mask_tile(t, kt, s);
-            psum[t] = 0.f; ptop[t] = 0u; ptopf[t] = 0.f;
+            psum[t] = 0.f;
         } else {
             exp_block(std::false_type{}, t, r - 1, 0.f, s, pf);
         }
@@ -1468,7 +1464,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
                 oacc[db][t][0] *= alpha; oacc[db][t][1] *= alpha;
                 oacc[db][t][2] *= alpha; oacc[db][t][3] *= alpha;
             }
-            psum[t] = 0.f; ptop[t] = 0u; ptopf[t] = 0.f;
+            psum[t] = 0.f;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 exp_block(std::true_type{}, t, kb, d, s, pf);
@@ -1537,14 +1533,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         // a p past the ceiling (wave-uniform test; the branch is cold)
         bool high = false;
 #pragma unroll
-        for (int t = 0; t < NTQ; ++t) {
-            if constexpr (P::kIsBF16) {
-                const uint32_t ceil = a.rebase_always ? P::kProbOne : P::kProbCeil;
-                high |= (ptop[t] & 0xffffu) > ceil || (ptop[t] >> 16) > ceil;
-            } else {
-                high |= ptopf[t] > (a.rebase_always ? 1.0f : 1.0e12f);
-            }
-        }
+        for (int t = 0; t < NTQ; ++t) high |= psum[t] > (a.rebase_always ? 1.0f : P::kProbCeil);
         if (__any(high)) rebase(scur, snext, pf);
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) lrun[t] += psum[t];
