@@ -363,7 +363,8 @@ def run_c4(args, rank, world, local_rank, use_dist):
     frames = torch.randint(50, 3001, (args.utterances,), generator=generator).tolist()
     shards = distributed.shard_lpt([data.flops(f) for f in frames], world)
     mine = shards[rank]
-    batches = data.pack_batches([frames[i] for i in mine], 32000)
+    # (row budget: no batch is one tile more than a whole round of the layer kernel's workgroups)
+    batches = data.pack_batches([frames[i] for i in mine], 32000, max_rows=data.row_budget(32000, gpu=local_rank))
     # this rank's padded batches, generated on its own GPU (nobody else ever holds them)
     device_generator = torch.Generator(device='cuda').manual_seed(1234 + rank)
     padded = []

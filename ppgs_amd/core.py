@@ -205,7 +205,8 @@ class loader:
         self.rates = [self.rates[i] for i in keep]
         if math.isinf(budget) and mode != 'reference':
             budget = max(DEFAULT_BATCH_FRAMES, max(self.frames, default=0))
-        self.batches = data.pack_batches(self.frames, budget, mode=mode)
+        rows = data.row_budget(budget) if mode == 'sorted' else None
+        self.batches = data.pack_batches(self.frames, budget, mode=mode, max_rows=rows)
         self.num_workers = max(int(num_workers), 1)
         self.dataset = self.files          # len(dataloader.dataset) as in the reference
 

@@ -40,27 +40,63 @@ def filter_lengths(lengths, max_frames, names=None):
     return keep
 
 
+def plan_rows(length, frames, chunk=config.CHUNK_LENGTH,
+              overlap=config.CHUNK_OVERLAP):
+    """Token rows one item of `length` valid frames occupies in the engine's
+    plan of a batch padded to `frames` (ppg_plan_windows, the reference's chunk
+    rule of transformer.py:49-64): every window of the batch grid that still
+    holds a valid frame of the item, each rounded up to 16 rows."""
+    if length <= 0:
+        return 0
+    if frames <= chunk:
+        return -(-frames // 16) * 16
+    stride = chunk - 2 * overlap
+    rows = 0
+    for index in range(-(-min(length, frames) // stride)):
+        start = index * stride
+        rows += -(-(min(start + chunk, frames + overlap) - start) // 16) * 16
+    return rows
+
+
+def row_budget(max_frames, tile_rows=160, gpu=None):
+    """Rows per batch for the packer on an engine pipeline: whole rounds of the
+    layer kernel's workgroups (one tile of `tile_rows` token rows per CU and
+    round; a batch of one tile more than a round costs a second round), as
+    many rounds as the frame budget's ~1.25 rows per frame fill.  None without
+    a GPU or for an unbounded budget."""
+    if not torch.cuda.is_available() or math.isinf(max_frames):
+        return None
+    device = torch.cuda.current_device() if gpu is None else gpu
+    per_round = torch.cuda.get_device_properties(device).multi_processor_count * tile_rows
+    return max(1, math.ceil(1.25 * max_frames / per_round)) * per_round
+
+
 def pack_batches(lengths, max_frames=config.MAX_INFERENCE_FRAMES,
                  mode='sorted', seed=config.RANDOM_SEED, epoch=0,
-                 buckets=config.BUCKETS):
+                 buckets=config.BUCKETS, max_rows=None):
     """Lists of indices such that len(batch) * max(len in batch) <= max_frames
     (a single item longer than the budget forms its own batch, as in the
-    reference sampler)."""
+    reference sampler).  `max_rows` (mode 'sorted' only; see row_budget) also
+    bounds the token rows of a batch's plan."""
     lengths = np.asarray(lengths, dtype=np.int64)
     count = len(lengths)
     if count == 0:
         return []
     if mode == 'sorted':
         order = np.argsort(lengths, kind='stable')
-        batches, batch, longest = [], [], 0
+        batches, batch, longest, rows = [], [], 0, 0
         for index in order[::-1]:           # longest first: max is the first item
             length = int(lengths[index])
             longest = max(longest, length)
-            if batch and (len(batch) + 1) * longest > max_frames:
+            item_rows = plan_rows(length, longest) if max_rows else 0
+            if batch and ((len(batch) + 1) * longest > max_frames or
+                          (max_rows and rows + item_rows > max_rows)):
                 batches.append(batch)
                 batch, longest = [int(index)], length
+                rows = plan_rows(length, length) if max_rows else 0
             else:
                 batch.append(int(index))
+                rows += item_rows
         if batch:
             batches.append(batch)
         return batches

@@ -138,7 +138,7 @@ def from_audios_sharded(audios, compute=None, gpu=None, max_frames=32000,
                 features, lengths // config.HOPSIZE,
                 representation=representation, checkpoint=checkpoint, gpu=gpu)
     results = {}
-    for batch in data.pack_batches([frames[i] for i in mine], max_frames):
+    for batch in data.pack_batches([frames[i] for i in mine], max_frames, max_rows=data.row_budget(max_frames, gpu=gpu)):
         indices = [mine[j] for j in batch]
         padded, lengths = data.collate([audios(i)[:1] for i in indices])
         out = compute(padded, lengths)

@@ -179,3 +179,32 @@ def test_bench_entry_point_fails_loudly_without_the_gpus():
     env = dict(os.environ, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0')
     run = subprocess.run([sys.executable, bench, '--gpus', '1'], capture_output=True, text=True, env=env)
     assert run.returncode != 0
+
+
+def test_plan_rows_and_row_budgeted_packing():
+    """data.plan_rows restates the planner's row count per item (ppg_plan_windows through the C ABI);
+    pack_batches(max_rows=...) keeps every batch's plan within the budget and the frame invariant."""
+    import random
+    from ppgs_amd import engine
+    rng = random.Random(3)
+    for _ in range(200):
+        frames = rng.choice([16, 100, 499, 500, 501, 850, 1000, 1234, 2999])
+        lengths = [frames] + [rng.randint(0, frames) for _ in range(rng.randint(0, 5))]
+        _, info = engine.plan_windows(len(lengths), frames, lengths)
+        assert info.tokens == sum(data.plan_rows(length, frames) for length in lengths), lengths
+    lengths = [rng.randint(50, 3000) for _ in range(2000)]
+    free = data.pack_batches(lengths, 32000)
+    bound = data.pack_batches(lengths, 32000, max_rows=40960)
+    assert sorted(i for b in bound for i in b) == list(range(len(lengths)))
+    over = 0
+    for batches, limit in ((free, None), (bound, 40960)):
+        for batch in batches:
+            longest = max(lengths[i] for i in batch)
+            assert len(batch) == 1 or len(batch) * longest <= 32000
+            _, info = engine.plan_windows(len(batch), longest, [lengths[i] for i in batch])
+            if limit:
+                assert info.tokens <= limit
+            else:
+                over += info.tokens > 40960
+    assert over > 0                      # the budget is what keeps them out, not the corpus
+    assert len(bound) <= len(free) + len(free) // 20 + 1
