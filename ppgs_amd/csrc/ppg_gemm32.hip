@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
-    u32x4 w1f[16], w2f[16];
+    // three register sets of 16 weight fragments; the third lives in the accumulation registers (an MFMA takes its
+    // A operand from either file, a global load writes either): with all three in the 256 architectural registers
+    // the compiler moved fragments between the files while their loads were still in flight
+    u32x4 w1f[16], w2f[16], w3f[16];
     auto load16 = [&](u32x4 (&wf)[16], const char* base) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
     };
@@ -71,19 +74,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     stash(0);
     if (chunks > 1) fetch(1);
     load16(w1f, wimg);
+    load16(w2f, wimg + (size_t)(chunks > 1 ? 1 : 0) * 16 * 1024);
     vm_wait_all(w1f);
+    vm_wait_all(w2f);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) asm volatile("" : "+v"(stg[i]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
     // chunk c from tile buffer c % 3 with the fragments in `cur`.  Its first act is to put the rows of chunk c + 1
-    // (requested a whole stream ago) into their buffer; the fragments of chunk c + 1 are requested on the even steps of
-    // the stream, the rows of chunk c + 2 on its last steps -- younger than the fragments, so that the wait for the
-    // fragments (vmcnt counts in order) leaves them in flight for another stream.
-    auto chunk = [&](int c, u32x4 (&cur)[16], u32x4 (&nxt)[16], auto first_tag) {
+    // (requested a whole stream ago) into their buffer.  On the first steps of its stream it requests the rows of
+    // chunk c + 2, then the fragments of chunk c + 2 into the register set chunk c - 1 used: both have a stream and
+    // more to land -- with fragments only ONE chunk ahead (and the rows requested at the END of the stream) every
+    // chunk waited out an L2 round trip: 2.6 us per 1 us of MFMAs at K = 3072.  vmcnt counts in order: at the end
+    // everything but the 16 youngest loads (those fragments) has landed.
+    auto chunk = [&](int c, u32x4 (&cur)[16], u32x4 (&nxt2)[16], auto first_tag, auto acc_file_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool TO_ACC = decltype(acc_file_tag)::value;      // nxt2 is the set kept in accumulation registers
         const bool more = c + 1 < chunks, more2 = c + 2 < chunks;
-        if (more) stash(c + 1);
-        const char* nbase = wimg + (size_t)(more ? c + 1 : c) * 16 * 1024;
+        if (more) stash(c + 1);     // (a store reads its data registers when it issues: the stream's first steps may reload them)
+        const char* nbase = wimg + (size_t)(more2 ? c + 2 : c) * 16 * 1024;
         const char* xnext = a.x + (size_t)(more2 ? c + 2 : c) * KC * 2 + scol;
         const uint32_t tile = rb0 + (uint32_t)((c % 3) * GBUF);
         constexpr int STEPS = KSC * GT;
@@ -97,27 +107,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 acc[0][tb] = P::mma32(cur[ks], bf, acc[0][tb]);
                 acc[1][tb] = P::mma32(cur[8 + ks], bf, acc[1][tb]);
             }
-            static_assert(STEPS >= 16 + NST, "16 fragment loads, then the row loads");
-            if constexpr (i < 16) gload_frag<i>(nxt[i], voff, nbase);
-            if constexpr (i >= STEPS - NST) {
-                constexpr int j = i - (STEPS - NST);
-                const int m = min(m0 + srow + 4 * j, a.M - 1);
-                stg[j] = *reinterpret_cast<const u32x4*>(xnext + (size_t)m * a.K * 2);
+            static_assert(STEPS >= 16 + NST, "the row loads, then 16 fragment loads");
+            if constexpr (i < NST) {
+                // (asm like the fragment loads: a load the compiler sees gets a compiler-made vmcnt wait at its
+                // use, counted without the asm loads in flight -- i.e. a wait for most of the fragments)
+                const int m = min(m0 + srow + 4 * i, a.M - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[i]) : "v"(xnext + (size_t)m * a.K * 2) : "memory");
+            } else if constexpr (i < NST + 16) {
+                constexpr int k = i - NST;
+                if constexpr (TO_ACC)
+                    gload128_acc<(k % 4) * 1024>(nxt2[k], voff, nbase + (k / 4) * 4096);
+                else
+                    gload_frag<k>(nxt2[k], voff, nbase);
             }
         });
-        // the fragments have landed once at most the NST younger row loads are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(nxt[i]));
+        for (int i = 0; i < NST; ++i) asm volatile("" : "+v"(stg[i]));
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    chunk(0, w1f, w2f, std::true_type{});
-    for (int c = 1; c < chunks; c += 2) {
-        chunk(c, w2f, w1f, std::false_type{});
-        if (c + 1 < chunks) chunk(c + 1, w1f, w2f, std::false_type{});
+    chunk(0, w1f, w3f, std::true_type{}, std::true_type{});
+    for (int c = 1; c < chunks; c += 3) {
+        chunk(c, w2f, w1f, std::false_type{}, std::false_type{});
+        if (c + 1 < chunks) chunk(c + 1, w3f, w2f, std::false_type{}, std::false_type{});
+        if (c + 2 < chunks) chunk(c + 2, w1f, w3f, std::false_type{}, std::true_type{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last chunks' clamped requests)
 
     // ---- epilogue: the lane's 16 consecutive features of its token, per (row block, token block)
     const int fbase = 256 * pass + 64 * wave;

@@ -52,6 +52,11 @@ template <int OFF>
 __device__ __forceinline__ void gload128(u32x4& dst, uint32_t voff, const char* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
+// ... into accumulation registers (gfx950 loads write either register file, MFMA operands come from either)
+template <int OFF>
+__device__ __forceinline__ void gload128_acc(u32x4& dst, uint32_t voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
 // fragment k of a run of fragments at `base` (the immediate reaches 4 KiB)
 template <int K>
 __device__ __forceinline__ void gload_frag(u32x4& dst, uint32_t voff, const char* base) {
