@@ -265,6 +265,7 @@ struct PpgEngine {
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool attn_xcd = true;    // attention items interleaved so that the query tiles of one (window, head) share an XCD's L2 (PPGS_AMD_ATTN_XCD=0: plain longest-first order)
+    bool outconv = true;     // output convolution with LDS-resident weights where it applies (ppg_outconv.hip; PPGS_AMD_OUTCONV=0: linear_kernel)
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
@@ -880,6 +881,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_OUTCONV")) e->outconv = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) e->l32_debug = atoi(v);
     if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) e->h32_debug = atoi(v);
     if (!e->layer32 || H != 256 || e->Cp != 96 || !e->qkv_fused) e->head32 = false;
@@ -1302,7 +1304,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
         if (e->lin_dbg_class == PPG_K_OUTCONV_SOFTMAX) a.dbg = e->lin_dbg;
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, lnt_ln, a, 1, s), "out-conv+softmax");
+        if (e->outconv && ppg::outconv_supported(prec, a)) LAUNCH_OK(ppg::launch_outconv(prec, a, s), "out-conv+softmax");
+        else LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, lnt_ln, a, 1, s), "out-conv+softmax");
     }
     return PPG_OK;
     };   // run_group

@@ -25,6 +25,9 @@ hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s);
 hipError_t launch_head32(int precision, const Head32Args& a, hipStream_t s);
 // the wide projections of the wav2vec2 body on the feature-split machinery (ppg_gemm32.hip): 16-bit precisions
 hipError_t launch_gemm32(int precision, const Gemm32Args& a, hipStream_t s);
+// output convolution + mask + softmax with the weights resident in LDS (ppg_outconv.hip): 16-bit precisions, hidden 256, whole batches
+bool outconv_supported(int precision, const LinearArgs& a);
+hipError_t launch_outconv(int precision, const LinearArgs& a, hipStream_t s);
 int layer32_tokens(int hidden);       // token rows per workgroup (160 at hidden 256, 96 at hidden 512)
 // wav2vec2 feature encoder, layer 0 (conv k10 s5 + GroupNorm + GELU; ppg_w2v2.hip) and the fp32 read-out of the last layer
 hipError_t launch_w2v2_layer0(int precision, const float* audio, int batch, long samples, long frames, int rows_per_item,

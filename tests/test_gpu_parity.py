@@ -371,6 +371,27 @@ def test_attention_rebase(monkeypatch, precision, causal):
         assert err.mean() < 1e-4 and np.quantile(err, 0.995) < 2e-3, (err.mean(), np.quantile(err, 0.995), err.max())
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_outconv_kernel_vs_linear_kernel(monkeypatch, precision):
+    """The output convolution with LDS-resident weights (ppg_outconv.hip, 16-bit modes at hidden 256)
+    against the generic k-tap kernel it replaces (PPGS_AMD_OUTCONV=0) and the oracle: ragged windows
+    (edges inside 16-token blocks, an exhausted item, T just past a window), posteriors and logits."""
+    lengths = [1130, 901, 500, 77, 0, 16]
+    gen = torch.Generator().manual_seed(123)
+    feats = torch.randn(len(lengths), 80, 1130, generator=gen).half()
+    state = W.seeded_state_dict(seed=1234)
+    fused = E.Engine(state, 0, precision)
+    monkeypatch.setenv('PPGS_AMD_OUTCONV', '0')
+    generic = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_OUTCONV')
+    ref = O.from_features(state, feats, lengths).numpy()
+    for softmax in (True, False):
+        a, b = run(fused, feats, lengths, softmax=softmax), run(generic, feats, lengths, softmax=softmax)
+        # same operands, another summation order of the 1280 products
+        assert np.isfinite(a).all() and np.abs(a - b).max() < (2e-5 if softmax else 2e-4)
+    assert np.abs(run(fused, feats, lengths) - ref).max() < TOL[precision]
+
+
 def test_unfused_ffn_path_agrees(monkeypatch):
     monkeypatch.setenv('PPGS_AMD_FFN_UNFUSED', '1')
     state = W.seeded_state_dict(seed=1234)
