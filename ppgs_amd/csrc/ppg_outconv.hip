@@ -122,13 +122,18 @@ __global__ __launch_bounds__(256) void outconv_kernel(LinearArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) waddr[nb] = lds0 + (uint32_t)((nb * 16 + idx) * WP + g * 16);
     const uint32_t xaddr = lds0 + (uint32_t)(L_TILE + (16 * wave + idx) * TP + g * 16);   // + tap * TP + (ks % 8) * 64
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();                       // the previous tile is consumed (first pass: the weights are in place)
+    // Order of a tile's memory operations (vmcnt retires in order, loads and stores alike): the rows of tile i + 1
+    // are written to LDS right after the MFMAs of tile i and BEFORE its output stores, the rows of tile i + 2 are
+    // requested after them -- a wait for rows then only ever waits for stores that are a whole tile old.
+    const int step = gridDim.x;
+    if ((int)blockIdx.x < ntiles) {
         stash();
-        const bool more = tile + (int)gridDim.x < ntiles;
-        if (more) fetch(tile + gridDim.x);
-        __syncthreads();
-        const int wnext = more ? lookup_block(tile + gridDim.x) : -1;
+        if ((int)blockIdx.x + step < ntiles) fetch(blockIdx.x + step);
+    }
+    __syncthreads();                           // weights and the first tile are in place
+    for (int tile = blockIdx.x; tile < ntiles; tile += step) {
+        const bool more = tile + step < ntiles;
+        const int wnext = more ? lookup_block(tile + step) : -1;
         const TokMeta tm = cur.tm;
         // taps inside the token's window, as a mask; blocks without an edge skip the per-lane selects
         unsigned taps_ok = 0;
@@ -170,8 +175,10 @@ __global__ __launch_bounds__(256) void outconv_kernel(LinearArgs a) {
             }(), ...);
         }(std::make_integer_sequence<int, NFRAG>{});
 
+        __syncthreads();                       // every wave has read this tile
+        if (more) stash();
         Meta nxt{};
-        if (more) nxt = lookup_window(tile + gridDim.x, wnext);
+        if (more) nxt = lookup_window(tile + step, wnext);
         // logits = (conv + bias) * mask; per-frame softmax over the out_C phonemes
         const bool live = tm.w >= 0 && tm.tt < tm.frames;
         const bool valid = live && tm.tt < tm.valid;
@@ -217,6 +224,8 @@ __global__ __launch_bounds__(256) void outconv_kernel(LinearArgs a) {
                     }
             }
         }
+        if (tile + 2 * step < ntiles) fetch(tile + 2 * step);
+        __syncthreads();                       // the next tile is in place
         cur = nxt;
     }
 }
