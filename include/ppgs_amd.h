@@ -214,7 +214,8 @@ int ppg_encode(PpgEngine* engine, const void* features, int feature_dtype,
  *   spec : device fp16 (batch, 513, samples/160) or NULL
  *   mel  : device fp16 (batch, 80, samples/160) or NULL
  * samples must be > 432 (reflect padding) -- same limit as torch's
- * reflection pad in the reference.
+ * reflection pad in the reference; batch * 513 * (samples / 160) must stay
+ * below 2^32 (the kernel indexes its outputs with 32 bits; PPG_EINVAL beyond).
  */
 int ppg_frontend(int device, const float* audio, int batch, int samples,
                  void* spec, void* mel, void* stream);

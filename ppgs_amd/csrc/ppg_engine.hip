@@ -2041,6 +2041,8 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
         ev = f->events[f->events_used++];
         on = hipEventRecord(ev.a, s) == hipSuccess;
     }
+    if ((double)batch * 513.0 * (double)(samples / 160) >= 4294967296.0)
+        return fail(PPG_EINVAL, "frontend: batch %d x 513 bins x %d frames does not fit the kernel's 32-bit output index", batch, samples / 160);
     hipError_t he = ppg::launch_frontend(f->tb, audio, batch, samples, spec, mel, s);
     if (on) (void)hipEventRecord(ev.b, s);
     if (f->tb.dbg) {
@@ -2050,7 +2052,7 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
             hipMemcpy(h, f->tb.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             for (int w = 0; w < 4; ++w) {
                 fprintf(stderr, "frontend wave %d (group 2 of workgroup 0):", w);
-                for (int k = 1; k < 10; ++k) fprintf(stderr, " [%d] %lld", k, (long long)(h[w * 16 + k] - h[w * 16]));
+                for (int k = 1; k < 7; ++k) fprintf(stderr, " [%d] %lld", k, (long long)(h[w * 16 + k] - h[w * 16]));
                 fprintf(stderr, "\n");
             }
         }
