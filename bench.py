@@ -25,6 +25,13 @@ rank generates and holds ONLY its shard; one step = one pass over the shard
 (frontend + encoder per packed batch); the final gatherv of the posteriors to
 rank 0 (RCCL) is timed separately (``gather_ms``).
 
+Between the W warm-up steps and the K timed steps the same step runs untimed for
+``--prewarm-s`` seconds (default 1.0, reported as ``prewarm_s``): the metric is the
+steady-state loop, and a GPU that was idle for a millisecond spends its next ~16 ms of
+load below its sustained clocks (tools/clock_series.py; round 2: the first 20-step
+block 0.837 ms/step, the next two 0.771 / 0.765 on the same box).  ``--prewarm-s 0``
+with ``--warmup 5`` times that ramp.
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the
 layer kernel): algorithmic FLOPs per launch / its mean launch duration
 measured with HIP events on the launch stream inside the timed region.
@@ -67,6 +74,10 @@ def parse(argv=None):
                         help='budget of the CPU-baseline leg')
     parser.add_argument('--no-cpu', action='store_true')
     parser.add_argument('--no-alt', action='store_true', help='skip the fp16-operand leg of c2')
+    parser.add_argument('--prewarm-s', type=float, default=1.0,
+                        help='c2: seconds of the same step run untimed after the W warm-up steps and before the '
+                             'timed K steps (the metric is the steady-state loop; a GPU that has been idle '
+                             'takes ~16 ms of load to reach its sustained clocks); reported as prewarm_s, 0 disables')
     args = parser.parse_args(argv)
     if args.steps is None:
         args.steps = 1000 if args.workload == 'c2' else 3      # ~1 s of timed work by default
@@ -141,12 +152,13 @@ def pmc_traffic(kernel):
     committed rocprofv3 PMC summary (profiles/r*_pmc_summary.txt; separate
     --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 reports half of
     a wide coalesced read, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB.
-    Not measurable inside this process: null when no summary names the kernel."""
+    PMC counters cannot be read inside this process, so the figure is NOT of the run that prints it: the
+    record names the file it was read from (`traffic_from`); null when no summary names the kernel."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.txt')))
     if not files:
-        return None
+        return None, None
     fetch = write = None
     lines = [line for line in open(files[-1]) if line.startswith(kernel)]
     # several variants of the kernel in one run: the one with the Q/K/V tail
@@ -158,8 +170,8 @@ def pmc_traffic(kernel):
         m = re.search(r'WRITE_SIZE=([0-9.e+]+)', line)
         write = float(m.group(1)) if m else write
     if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
 ###############################################################################
@@ -213,17 +225,42 @@ def run_c2(args, rank, world, local_rank, use_dist):
             elapsed = float(worst.item())
         return elapsed, out
 
+    def prewarm(engine=model):
+        """Disclosed, untimed: the same step for >= --prewarm-s seconds of wall time, so that the K timed
+        steps see the steady-state clocks of a loaded GPU (the metric is the steady-state
+        loop) instead of the ramp of a chip that was idle a moment ago."""
+        steps, start = 0, time.perf_counter()
+        while args.prewarm_s > 0 and time.perf_counter() - start < args.prewarm_s:
+            for _ in range(20):
+                step(engine)
+            torch.cuda.synchronize()
+            steps += 20
+        return steps, time.perf_counter() - start
+
     out = step()                         # setup: window plan built and uploaded, workspace allocated
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    # (the first torch kernel of the process loads torch's code objects: tens of milliseconds of idle GPU --
+    # here, not between the warm-up and the timed region)
     assert out.shape == (BATCH, 40, FRAMES) and bool(torch.isfinite(out).all())
+    # the events of the roofline leg exist before the timed region starts
+    model.profile(True, classes=['ffn'], stride=EVENT_STRIDE)
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
+    model.profile_read()
+    barrier()                            # (N > 1: RCCL builds its communicator on the first collective, not in the timed region)
+    # Nothing may idle the GPU between here and the timed region: after ~1 ms without work the chip drops its
+    # clocks and needs ~16 ms of load to get them back (tools/clock_series.py: first 20-step block after an idle
+    # gap 0.81 - 0.83 ms/step, every later one 0.74) -- a 20-step timed region IS 16 ms.
+    prewarm_steps, prewarm_seconds = prewarm()
+    model.profile(True, classes=['ffn'], stride=EVENT_STRIDE)         # (reset of the counters: two ctypes calls)
 
     # timed region: HIP events only around the dominant kernel (roofline leg)
     # (every 6th launch: 6 is coprime with the 5 layers, so the samples rotate
     # through the five launches of a step; two event records per launch cost
     # ~1.5 us each on the stream, 1.5 % of the step if every launch is timed)
-    model.profile(True, classes=['ffn'], stride=EVENT_STRIDE)
     elapsed, out = timed_block()
     ffn_ms, ffn_samples = model.profile_read()['ffn']
     model.profile(False)
@@ -260,6 +297,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
         other = E.Engine(state, local_rank, 'fp16')
         for _ in range(max(args.warmup, 3)):
             step(other)
+        prewarm(other)
         alt_elapsed, alt_out = timed_block(other)
         alt = {'dtype': 'fp16 operands, fp32 accumulate', 'ms_per_step': 1e3 * alt_elapsed / args.steps,
                'value': BATCH * FRAMES * args.steps / alt_elapsed,
@@ -277,6 +315,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
             del os.environ['PPGS_AMD_STREAMS']
         for _ in range(max(args.warmup, 3)):
             step(other)
+        prewarm(other)
         s2_elapsed, s2_out = timed_block(other)
         alt_streams = {'streams': 2, 'ms_per_step': 1e3 * s2_elapsed / args.steps,
                        'value': BATCH * FRAMES * args.steps / s2_elapsed,
@@ -295,6 +334,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
     peak = PEAK_FP32_TFLOPS if args.precision == 'fp32' else PEAK_16BIT_TFLOPS
     step_flops = BATCH * data.flops(FRAMES)
     layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
+    traffic, traffic_from = pmc_traffic('layer32_' if layer32 else 'ffn_')
     kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
                    'W1+ReLU+W2+residual+LN2' + (', next layer Q/K/V)' if qkv_fused_layers else ')')) if layer32 else (
         'ffn_mixed_kernel (token-split layer kernel: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
@@ -307,6 +347,8 @@ def run_c2(args, rank, world, local_rank, use_dist):
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
+        'prewarm_s': prewarm_seconds,
+        'prewarm_steps': prewarm_steps,
         'ms_per_step': ms_per_step,
         'higher_is_better': True,
         'scaling': 'weak',
@@ -328,7 +370,9 @@ def run_c2(args, rank, world, local_rank, use_dist):
             'peak': peak,
             'unit': 'TFLOP/s',
             'frac': ffn_tflops / peak,
-            'traffic': pmc_traffic('layer32_' if layer32 else 'ffn_'),
+            'traffic': traffic,
+            'traffic_from': traffic_from and f'{traffic_from} (committed rocprofv3 --pmc passes of this command, '
+                                             'not this run)',
             'flops_per_launch': ffn_flops,
             'mean_launch_ms': ffn_ms / max(ffn_samples, 1),
             'timed_launches': ffn_samples,

@@ -121,7 +121,7 @@ def from_file(file, representation=config.REPRESENTATION, checkpoint=None,
               gpu=None, legacy_mode=False):
     """Infer ppgs from an audio file -> (40, frames)
     (reference ppgs/core.py:131-168)."""
-    audio = load.audio(file)
+    audio = load.audio(file, gpu=gpu)
     return from_audio(
         audio=audio[None] if audio.dim() == 2 else audio,
         sample_rate=config.SAMPLE_RATE, representation=representation,
@@ -162,7 +162,7 @@ def from_files_to_files(audio_files, output_files,
         return
     dataloader = loader(
         audio_files, num_workers=max(num_workers // 2, 1),
-        max_frames=max_frames, mode=PACKING_MODE)
+        max_frames=max_frames, mode=PACKING_MODE, gpu=gpu)
     mapping = dict(zip(audio_files, output_files))
     from_dataloader(
         dataloader=dataloader, output_files=mapping,
@@ -181,8 +181,9 @@ class loader:
     features=['audio','length','audio_file'] (ppgs/data/loader.py:20-43)."""
 
     def __init__(self, audio_files, num_workers=1,
-                 max_frames=config.MAX_INFERENCE_FRAMES, mode='sorted'):
+                 max_frames=config.MAX_INFERENCE_FRAMES, mode='sorted', gpu=None):
         self.files = list(audio_files)
+        self.gpu = gpu                     # the device that resamples files that are not at 16 kHz
         frames, self.samples, self.rates = [], [], []
         readable = []
         for file in self.files:
@@ -223,7 +224,7 @@ class loader:
             padded, lengths, _ = engine.wav_read_batch(
                 files, longest, threads=self.num_workers)
             return padded, lengths, tuple(files)
-        audios = [load.audio(file)[:1] for file in files]
+        audios = [load.audio(file, gpu=self.gpu)[:1] for file in files]
         padded, lengths = data.collate(audios)
         return padded, lengths, tuple(files)
 
@@ -334,8 +335,20 @@ def infer(features, lengths, representation='mel', checkpoint=None,
         features, lengths, softmax=softmax, legacy_mode=legacy_mode)
 
 
-def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE):
-    """Perform audio resampling (reference ppgs/core.py:599-608).
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for host-tensor conversions (file loading in a background
+    thread must not queue behind -- or in front of -- the pipelines' kernels on the default stream)."""
+    if device.index not in _side_streams:
+        _side_streams[device.index] = torch.cuda.Stream(device)
+    return _side_streams[device.index]
+
+
+def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE, gpu=None):
+    """Perform audio resampling (reference ppgs/core.py:599-608; `gpu` is this package's
+    addition: which HIP device converts a HOST tensor -- default the current one).
 
     Identity at 16 kHz.  Otherwise torchaudio.transforms.Resample's default
     windowed-sinc polyphase filter (Hann window, lowpass_filter_width 6,

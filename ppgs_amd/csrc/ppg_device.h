@@ -275,7 +275,7 @@ struct LinearArgs {
     const PpgWindow* win;
     int M;                    // rows in the token-major buffers (multiple of 16)
     unsigned long long* dbg;  // PPG_LIN_TIMING builds: 16 s_memtime stamps per workgroup (tools/lin_timing.py)
-    int x_tiled;              // EPI_INCONV: X is written in X32 order (the layer32 kernel follows)
+    int x_tiled;              // EPI_INCONV: X is written in X32 order (1) or as fp16 in X16 order (2): the layer32 kernel follows
     int stride;               // EPI_GELU: output row m reads input rows stride * m + tap, tap = 0 .. taps - 1
     int M_in;                 // EPI_GELU: rows of the input buffer
     // EPI_GENERAL
@@ -331,6 +331,15 @@ __host__ __device__ inline size_t x32_index(int m, int n, int hidden) {        /
     const int w = n / (32 * RB), rb = (n >> 5) % RB, hh = (n >> 4) & 1, q = (n >> 2) & 3;
     return ((((((size_t)tile * 4 + w) * TB + tb) * RB + rb) * 4 + q) * 64 + hh * 32 + tok) * 4 + (n & 3);
 }
+// X16: the same stream as fp16 (the bf16 mode's residual stream between two layer kernels: half the bytes of the
+// layer kernel's two chip-wide bursts; 11 significand bits against the mode's 8-bit operands): the 8 halves
+// (token m, features n..n+7 of a 16-feature run) are one 16-byte lane slot of a KiB per (token block, row block, half)
+__host__ __device__ inline size_t x16_index(int m, int n, int hidden) {        // half index of X[m][n]
+    const int toks = layer32_tile_tokens(hidden), RB = hidden / 128, TB = toks / 32;
+    const int tile = m / toks, r = m - tile * toks, tb = r >> 5, tok = r & 31;
+    const int w = n / (32 * RB), rb = (n >> 5) % RB, hh = (n >> 4) & 1, s = (n >> 3) & 1;
+    return ((((((size_t)tile * 4 + w) * TB + tb) * RB + rb) * 2 + s) * 64 + hh * 32 + tok) * 8 + (n & 7);
+}
 __host__ __device__ inline size_t ao32_byte(int m, int n, int hidden) {        // byte offset of AO[m][n], n % 8 == 0, 16-bit elements
     const int toks = layer32_tile_tokens(hidden), KS = hidden / 16, TB = toks / 32;
     const int tile = m / toks, r = m - tile * toks, tb = r >> 5, tok = r & 31;
@@ -364,6 +373,7 @@ struct Layer32Args {
     unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
     int debug_mode;           // PPGS_AMD_L32_DEBUG (bisecting): bit 0 skip the out-projection, bit 1 skip the FFN
     int write_x;              // 0: the fp32 result is not stored (last layer: only the 16-bit copy is read afterwards)
+    int x_half;               // 1: X is the fp16 stream in X16 order (see x16_index) instead of fp32 in X32 order
 };
 
 // One attention workgroup's work: a query tile of one window.  The window fields
@@ -468,6 +478,7 @@ struct Head32Args {
     int vt_tokens;
     char* qk_slack;
     int qk_slack_bytes;
+    int x_half;               // 1: X is written as fp16 in X16 order (see x16_index)
     int debug_mode;           // timing experiments (wrong results): 1 no convolution, 2 no Q/K/V, 4 no gather
     unsigned long long* dbg;  // PPGS_AMD_H32_TIMING=1: s_memtime stamps of workgroup 0, [wave][16]
 };

@@ -269,6 +269,7 @@ struct PpgEngine {
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
+    bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
@@ -331,8 +332,8 @@ struct PpgEngine {
                 if (layer32) {
                     for (int w = 0; w < 4; ++w) {
                         const unsigned long long* t = h + w * 8;
-                        fprintf(stderr, "layer32 wave %d chunk 4: phase A %llu  barrier %llu  pack+write %llu  barrier %llu  phase B %llu | total %llu\n",
-                                w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+                        fprintf(stderr, "layer32 wave %d chunk 4 (hidden 256: one stream): A blocks 0-2 %llu  A blocks 3,4 + h writes %llu  B blocks 0-2 + h writes %llu  B blocks 3,4 %llu | total %llu\n",
+                                w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[5] - t[3], t[5] - t[0]);
                     }
                 } else
                 for (int w = 0; w < 4; ++w)
@@ -881,6 +882,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
+    e->x16 = cfg->precision == PPG_PRECISION_BF16;
+    if (const char* v = getenv("PPGS_AMD_X16")) e->x16 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_OUTCONV")) e->outconv = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) e->l32_debug = atoi(v);
     if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) e->h32_debug = atoi(v);
@@ -1180,6 +1183,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.nwin = (int)grp.windows.size(); a.vt_rows = H; a.vt_tokens = grp.vt_tokens;
         a.qk_slack = qk + (size_t)M * 2 * H * e->sz; a.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
         a.debug_mode = e->h32_debug;
+        a.x_half = e->x16;
         a.dbg = e->head_dbg;
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
@@ -1204,7 +1208,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     if (!head) {
         Timed t(e, PPG_K_INCONV, s);
         LinearArgs a = base_args();
-        a.x_tiled = use32;
+        a.x_tiled = use32 ? (e->x16 ? 2 : 1) : 0;
         a.act = xw; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
         a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
         a.total_groups = e->in_total_groups;
@@ -1242,6 +1246,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2;
             a.X = X; a.Xb = Xb; a.M = M; a.F = F; a.H = H; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
             a.debug_mode = e->l32_debug;
+            a.x_half = e->x16;
             qkv_done = e->qkv_fused && l + 1 < c.num_layers;
             a.write_x = l + 1 < c.num_layers;
             if (qkv_done) {
@@ -2064,6 +2069,16 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
 int ppg_engine_profile(PpgEngine* e, int enable) {
     if (!e) return fail(PPG_EINVAL, "null engine");
     e->profiling = (unsigned)enable;
+    // a first pool of event pairs per enabled class, so that a short timed region does not pay for creating them
+    if (enable) (void)hipSetDevice(e->device);
+    for (int cls = 0; enable && cls < PPG_K_COUNT; ++cls) {
+        if (!(e->profiling & (1u << cls))) continue;
+        while (e->events[cls].size() < 32) {
+            EventPair p;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) break;
+            e->events[cls].push_back(p);
+        }
+    }
     return PPG_OK;
 }
 

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(4);
     // ---- 3. x = live ? PE[tt] + (valid ? y + bias : 0) : 0 (as linear_kernel<EPI_INCONV>) -> X32 and the panel
     float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 4 * 256) + lane * 4;
+    char* xh = reinterpret_cast<char*>(a.X) + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 2 * 1024) + lane * 16;   // X16 order
     auto emit = [&](auto rb_tag) {
         constexpr int rb = decltype(rb_tag)::value;
         const int f0 = fbase + 32 * rb + 16 * hh;            // the lane's 16 consecutive features of the block
@@ -221,7 +222,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 y[4 * q + 1] = live[t] ? pv[t][q].y + (valid[t] ? yacc[rb][t][4 * q + 1] + bias[q].y : 0.f) : 0.f;
                 y[4 * q + 2] = live[t] ? pv[t][q].z + (valid[t] ? yacc[rb][t][4 * q + 2] + bias[q].z : 0.f) : 0.f;
                 y[4 * q + 3] = live[t] ? pv[t][q].w + (valid[t] ? yacc[rb][t][4 * q + 3] + bias[q].w : 0.f) : 0.f;
-                *reinterpret_cast<float4*>(xt + ((t * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                if (!a.x_half)
+                    *reinterpret_cast<float4*>(xt + ((t * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+            }
+            if (a.x_half) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    *reinterpret_cast<u32x4*>(xh + ((t * RB + rb) * 2 + s2) * 1024) = u32x4{pack_f16x2(y[8 * s2 + 0], y[8 * s2 + 1]), pack_f16x2(y[8 * s2 + 2], y[8 * s2 + 3]),
+                                                                                      pack_f16x2(y[8 * s2 + 4], y[8 * s2 + 5]), pack_f16x2(y[8 * s2 + 6], y[8 * s2 + 7])};
             }
             panel_store<P, HID>(pb0, wave, t, rb, y);
         }

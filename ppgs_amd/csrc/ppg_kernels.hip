@@ -540,7 +540,10 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 y.w = live[t] ? pv.w + (valid[t] ? acc[nb][t][3] + bv.w : 0.f) : 0.f;
                 if (inside[t]) {
                     const int m = tok0 + 16 * t + idx;
-                    *reinterpret_cast<float4*>(a.X + (a.x_tiled ? x32_index(m, n, a.H) : (size_t)m * a.H + n)) = y;
+                    if (a.x_tiled == 2)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.X) + x16_index(m, n, a.H)) = make_uint2(pack_f16x2(y.x, y.y), pack_f16x2(y.z, y.w));
+                    else
+                        *reinterpret_cast<float4*>(a.X + (a.x_tiled ? x32_index(m, n, a.H) : (size_t)m * a.H + n)) = y;
                     if constexpr (P::kIsBF16) pair[t].put(a.Xb + ((size_t)m * a.H + (n & ~7)) * 2, nb & 1, y.x, y.y, y.z, y.w);
                 }
             }

@@ -114,6 +114,19 @@ struct OffPanel { static constexpr int at(int i) { return ((TB0 + i % NTB) * KS 
 template <int TBN>
 struct OffH { static constexpr int at(int i) { return ((i % TBN) * 8 + i / TBN) * 1024; } };
 
+// The hidden-256 layer kernel's FFN chunk as ONE stream (see ppg_layer32.hip): steps 0..47 phase A on token blocks
+// 0..2 (panel fragment (tb, ks), ks outer), 48..79 phase A on blocks 3, 4, 80..103 phase B on blocks 0..2 (h fragment
+// (tb, ks), ks outer), 104..119 phase B on blocks 3, 4; offsets from the panel base (h lies behind the panel)
+struct OffChunk256 {
+    static constexpr int at(int i) {
+        constexpr int KS = Geo<256>::KS, HOFF = Geo<256>::L_H - Geo<256>::L_ACT;
+        if (i < 48) return ((i % 3) * KS + i / 3) * 1024;
+        if (i < 80) return ((3 + (i - 48) % 2) * KS + (i - 48) / 2) * 1024;
+        if (i < 104) return HOFF + (((i - 80) % 3) * 8 + (i - 80) / 3) * 1024;
+        return HOFF + ((3 + (i - 104) % 2) * 8 + (i - 104) / 2) * 1024;
+    }
+};
+
 __device__ __forceinline__ float pair_sum(float v) {          // lanes l and l + 32
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
@@ -136,10 +149,27 @@ __device__ __forceinline__ void panel_store(uint32_t pb0, int wave, int t, int r
 // Q/K/V projection of the tile's tokens, x in the token panel (every wave's panel_store done or in flight: the
 // function starts with the barrier), W_qkv fragments of half-step 0 already in w1f.  Stores Q | K row-major and
 // V transposed in attn_kernel's layouts.
+//
+// 3 RB steps of one 32-row block each: Q and K features of this wave (row-major stores, a lane owns 16 consecutive
+// features of its token) and its V features with the MFMA operands swapped, so that the accumulator comes out
+// transposed for V^T (a lane owns one V^T row and 16 tokens).  Every step takes KH half-steps of 16 W fragments
+// (image order [wave][step][ks]); the two register sets alternate: the next half-step's fragments travel under
+// this one's MFMAs.  The steps are software-pipelined over TWO accumulator sets (everything else of the kernel is
+// dead by now): the epilogue of step k -- bias, pack, global stores -- is issued between the MFMAs of step k + 1's
+// first half-step, behind that half-step's fragment requests.  vmcnt counts loads and stores in issue order, so
+// the wait for the fragments at the end of a half-step is `vmcnt(stores issued after the last request)`: it does
+// not wait for the acknowledgement of the stores (the whole chip stores at once: that was 0.4 - 1.3 k cycles per
+// step, on top of 1.4 - 3.2 k cycles of epilogue with the matrix pipe idle).  The count is exact only in a tile
+// whose rows all exist and whose token blocks are whole 32-token groups of V^T (`regular`: every tile of a
+// batch of 32-aligned windows); any other tile waits with vmcnt(0).
 template <class P, int HIDT>
 __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const int m0, u32x4 (&w1f)[16], u32x4 (&w2f)[16]) {
     using G = Geo<HIDT>;
-    constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN;
+    constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
+    constexpr int NSTEP = 3 * RB, NHS = NSTEP * KH;
+    constexpr int NMMA = 16 * TB;                           // MFMAs (= stream steps) of a half-step
+    constexpr int NU = 2 * TB;                              // epilogue units (one 16-byte store each in a regular tile)
+    constexpr int USTRIDE = (NMMA - 16) / NU;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tok = lane & 31, hh = lane >> 5;
@@ -147,18 +177,13 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
     const uint32_t pb0 = lds_addr32(smem) + G::L_ACT + lane * 16, pb1 = pb0 + 65536;
     const int fbase = 32 * RB * wave;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // ---- the next layer's Q/K/V projection on x2 ------------------------------------------
-    // 3 RB steps of one 32-row block each: Q and K features of this wave (row-major stores, a lane
-    // owns 16 consecutive features of its token) and its V features with the MFMA operands swapped,
-    // so that the accumulator comes out transposed for V^T (a lane owns one V^T row and 16 tokens).
-    // Every step takes KH half-steps of 16 W fragments (image order [wave][step][ks]); the two register
-    // sets alternate: the next half-step's fragments travel under this one's MFMAs.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                       // x2 panel complete
     const float* bq = reinterpret_cast<const float*>(smem + G::L_BQ);
     // transposed-V columns of the wave-uniform 16-token halves of every token block
     int vcol[TB][2];
     bool valigned[TB];
+    bool regular = m0 + TOKS <= a.M;
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
 #pragma unroll
@@ -174,91 +199,106 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             }
         }
         valigned[t] = vcol[t][0] >= 0 && vcol[t][1] == vcol[t][0] + 4 && (vcol[t][0] & 31) == 0;
+        regular = regular && valigned[t];
     }
     const char* wq = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
-    f32x16 acc[TB];
-    auto half_step = [&](auto hs_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
-        constexpr int HS = decltype(hs_tag)::value;
-        constexpr int STEP = HS / KH, kh = HS % KH;
-        constexpr int KIND = STEP / RB, RBI = STEP % RB;        // 0 Q, 1 K, 2 V; row block inside the wave's features
-        constexpr bool SWAP = KIND == 2;
-        constexpr bool LAST = HS + 1 == 3 * RB * KH;
-        const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
-#ifdef PPG_FFN_TIMING
-        auto tstamp = [&](int k) { if (a.dbg && blockIdx.x == 0 && lane == 0 && wave == 0 && HS < 6) a.dbg[192 + HS * 8 + k] = __builtin_amdgcn_s_memtime(); };
-#else
-        auto tstamp = [&](int) {};
-#endif
-        tstamp(0);
-        stream<OffPanel<KS, 16 * kh, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int ks = i / TB, tb = i % TB;
-            if constexpr (ks == 0 && kh == 0) acc[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
-            else acc[tb] = SWAP ? P::mma32(bf, cur[ks], acc[tb]) : P::mma32(cur[ks], bf, acc[tb]);
-            // the next half-step's fragments: issued in the first three fifths of the stream so that ...
-            if constexpr (!LAST && i % 3 == 0 && i / 3 < 16) gload_frag<i / 3>(nxt[i / 3], voff, nbase);
-        });
-        // ... they have landed here: the epilogue below is ordinary compiler code, which may move or
-        // spill registers it believes ready (an asm load's destination must be waited for before that)
-        tstamp(1);
-        if constexpr (!LAST) vm_wait_all(nxt);
-        tstamp(2);
-        if constexpr (kh + 1 < KH) return;
-        if constexpr (!SWAP) {
-            // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh .. + 15
-            constexpr int n0 = HIDT * KIND + 32 * RBI;
-            float4 b4[4];
+    f32x16 acc[2][TB];
+    // the lane's bias values of a step's epilogue: 16 consecutive features (Q / K) or one V^T row
+    auto bias_of = [&](auto step_tag, float4 (&b4)[4]) {
+        constexpr int STEP = decltype(step_tag)::value, KIND = STEP / RB, RBI = STEP % RB;
+        if constexpr (KIND < 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bq + n0 + fbase + 16 * hh + 4 * q);
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int m = m0 + 32 * t + tok;
-                if (m >= a.M) continue;
-                char* dst = a.qk_out + ((size_t)m * 2 * HIDT + n0 + fbase + 16 * hh) * 2;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
-                    *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{
-                        P::pack2(acc[t][8 * s2 + 0] + ba.x, acc[t][8 * s2 + 1] + ba.y), P::pack2(acc[t][8 * s2 + 2] + ba.z, acc[t][8 * s2 + 3] + ba.w),
-                        P::pack2(acc[t][8 * s2 + 4] + bb.x, acc[t][8 * s2 + 5] + bb.y), P::pack2(acc[t][8 * s2 + 6] + bb.z, acc[t][8 * s2 + 7] + bb.w)};
-                }
+            for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(bq + HIDT * KIND + 32 * RBI + fbase + 16 * hh + 4 * q);
+        } else {
+            const float bv = bq[2 * HIDT + pair_row(fbase + 32 * RBI + tok)];
+            b4[0] = make_float4(bv, bv, bv, bv);
+        }
+    };
+    // epilogue unit U (token block U / 2, half U % 2) of step STEP from its accumulator set
+    auto unit = [&](auto step_tag, auto u_tag, const float4 (&b4)[4]) {
+        constexpr int STEP = decltype(step_tag)::value, U = decltype(u_tag)::value;
+        constexpr int KIND = STEP / RB, RBI = STEP % RB, t = U / 2, s2 = U % 2;
+        const f32x16& c = acc[STEP & 1][t];
+        if constexpr (KIND < 2) {
+            // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh + 8 s2 .. + 7
+            const int m = m0 + 32 * t + tok;
+            if (m < a.M) {
+                char* dst = a.qk_out + ((size_t)m * 2 * HIDT + HIDT * KIND + 32 * RBI + fbase + 16 * hh) * 2;
+                const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
+                *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{
+                    P::pack2(c[8 * s2 + 0] + ba.x, c[8 * s2 + 1] + ba.y), P::pack2(c[8 * s2 + 2] + ba.z, c[8 * s2 + 3] + ba.w),
+                    P::pack2(c[8 * s2 + 4] + bb.x, c[8 * s2 + 5] + bb.y), P::pack2(c[8 * s2 + 6] + bb.z, c[8 * s2 + 7] + bb.w)};
             }
         } else {
-            // V: lane = V^T row fbase + 32 RBI + (l & 31) (natural feature pair_row(row): attn_kernel's
-            // tile order), registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of
-            // every 32-token group of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
-            const int vrow = fbase + 32 * RBI + tok;
-            const float bv = bq[2 * HIDT + pair_row(vrow)];
-            char* rowp = a.vt_out + (size_t)vrow * a.vt_ld * 2;
+            // V: lane = V^T row fbase + 32 RBI + (l & 31) (natural feature pair_row(row): attn_kernel's tile order),
+            // registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of every 32-token group
+            // of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
+            const float bv = b4[0].x;
+            char* rowp = a.vt_out + (size_t)(fbase + 32 * RBI + tok) * a.vt_ld * 2;
+            if (valigned[t]) {            // the block is one 32-token group: (q, q + 2) are 8 consecutive columns
+                *reinterpret_cast<u32x4*>(rowp + (size_t)(vcol[t][0] + 16 * s2 + 8 * hh) * 2) = u32x4{
+                    P::pack2(c[4 * s2 + 0] + bv, c[4 * s2 + 1] + bv), P::pack2(c[4 * s2 + 2] + bv, c[4 * s2 + 3] + bv),
+                    P::pack2(c[4 * (s2 + 2) + 0] + bv, c[4 * (s2 + 2) + 1] + bv), P::pack2(c[4 * (s2 + 2) + 2] + bv, c[4 * (s2 + 2) + 3] + bv)};
+            } else if (vcol[t][s2] >= 0) {    // (half s2 of the block: tokens 16 s2 .., registers q = 2 s2, 2 s2 + 1)
 #pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                if (valigned[t]) {        // the block is one 32-token group: (q, q + 2) are 8 consecutive columns
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-                        *reinterpret_cast<u32x4*>(rowp + (size_t)(vcol[t][0] + 16 * s2 + 8 * hh) * 2) = u32x4{
-                            P::pack2(acc[t][4 * s2 + 0] + bv, acc[t][4 * s2 + 1] + bv), P::pack2(acc[t][4 * s2 + 2] + bv, acc[t][4 * s2 + 3] + bv),
-                            P::pack2(acc[t][4 * (s2 + 2) + 0] + bv, acc[t][4 * (s2 + 2) + 1] + bv), P::pack2(acc[t][4 * (s2 + 2) + 2] + bv, acc[t][4 * (s2 + 2) + 3] + bv)};
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (vcol[t][h] < 0) continue;
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const int q = 2 * h + s2;
-                            *reinterpret_cast<uint2*>(rowp + (size_t)(vcol[t][h] + 8 * (2 * s2 + hh)) * 2) = make_uint2(
-                                P::pack2(acc[t][4 * q + 0] + bv, acc[t][4 * q + 1] + bv), P::pack2(acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv));
-                        }
-                    }
+                for (int e = 0; e < 2; ++e) {
+                    const int q = 2 * s2 + e;
+                    *reinterpret_cast<uint2*>(rowp + (size_t)(vcol[t][s2] + 8 * (2 * e + hh)) * 2) = make_uint2(
+                        P::pack2(c[4 * q + 0] + bv, c[4 * q + 1] + bv), P::pack2(c[4 * q + 2] + bv, c[4 * q + 3] + bv));
                 }
             }
         }
-        tstamp(3); tstamp(4); tstamp(5);
+    };
+    float4 b4[4];
+    auto half_step = [&](auto hs_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
+        constexpr int HS = decltype(hs_tag)::value;
+        constexpr int STEP = HS / KH, kh = HS % KH;
+        constexpr bool SWAP = STEP / RB == 2;
+        constexpr bool LAST = HS + 1 == NHS;
+        constexpr bool EPI = kh == 0 && STEP > 0;            // the previous step's epilogue rides along
+        const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
+        if constexpr (EPI) {
+            // (LDS reads by compiler code: waited for HERE, not in the middle of the stream where the compiler's
+            // lgkmcnt(0) would drain the fragment ring)
+            bias_of(std::integral_constant<int, STEP - 1>{}, b4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(b4[q].x), "+v"(b4[q].y), "+v"(b4[q].z), "+v"(b4[q].w));
+        }
+        f32x16 (&c)[TB] = acc[STEP & 1];
+        stream<OffPanel<KS, 16 * kh, 0, TB>, NMMA, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int ks = i / TB, tb = i % TB;
+            if constexpr (ks == 0 && kh == 0) c[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
+            else c[tb] = SWAP ? P::mma32(bf, cur[ks], c[tb]) : P::mma32(cur[ks], bf, c[tb]);
+            // the next half-step's fragments first, the previous step's stores behind them
+            if constexpr (!LAST && i < 16) gload_frag<i>(nxt[i], voff, nbase);
+            if constexpr (EPI && i >= 16 && (i - 16) % USTRIDE == 0 && (i - 16) / USTRIDE < NU)
+                unit(std::integral_constant<int, STEP - 1>{}, std::integral_constant<int, (i - 16) / USTRIDE>{}, b4);
+        });
+        // the fragments have landed (registers an asm load writes must be waited for before compiler code may touch them)
+        if constexpr (!LAST) {
+            if constexpr (EPI) {
+                if (regular) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NU) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(nxt[k]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // (half-step 0's fragments arrived in set 1 with the last FFN chunk)
     [&]<int... S>(std::integer_sequence<int, S...>) {
         ((S % 2 == 0 ? half_step(std::integral_constant<int, S>{}, w1f, w2f)
                      : half_step(std::integral_constant<int, S>{}, w2f, w1f)), ...);
-    }(std::make_integer_sequence<int, 3 * RB * KH>{});
+    }(std::make_integer_sequence<int, NHS>{});
+    // the last step's epilogue
+    bias_of(std::integral_constant<int, NSTEP - 1>{}, b4);
+    (void)TOKS;
+    [&]<int... U>(std::integer_sequence<int, U...>) {
+        (unit(std::integral_constant<int, NSTEP - 1>{}, std::integral_constant<int, U>{}, b4), ...);
+    }(std::make_integer_sequence<int, NU>{});
 }
 
 }  // namespace

@@ -66,6 +66,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto load16 = [&](u32x4 (&wf)[16], const char* base) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
     };
+    // ---- the residual rows, when they are fp16 (X16 order: 20 KiB per wave = 80 registers): requested before anything
+    // else, they travel under the attention-output DMA, the W_o fetch and the out-projection.  (Loaded inside
+    // LayerNorm-1 the compiler can afford one token block's worth of registers at a time: five dependent round trips
+    // of ~2.5 k cycles each while the whole chip does the same -- 12.9 k of the kernel's 200 k cycles.  As fp32 the rows
+    // are 160 registers per lane, which the out-projection cannot spare.)  The W_o wait below (vmcnt(0)) covers them.
+    constexpr bool XPRE = HIDT == 256;
+    constexpr int NRES = XPRE ? TB * RB * 2 : 1;
+    u32x4 res[NRES];
+    const bool xpre = XPRE && a.x_half;
+    if (xpre) {
+        const char* xbase = reinterpret_cast<const char*>(a.X) + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 2 * 1024);
+        [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(res[K], voff, xbase), ...); }(std::make_integer_sequence<int, NRES>{});
+    }
     // ---- attention output (AO32 order: this tile's fragments are one contiguous block) -> LDS panel
     {
         const char* tile = a.ao + (size_t)blockIdx.x * (TB * KS * 1024);
@@ -122,6 +135,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             vm_wait_all(w1f);
             vm_wait_all(w2f);
             if constexpr (R == 0) {
+#pragma unroll
+                for (int k = 0; k < NRES; ++k) asm volatile("" : "+v"(res[k]));
                 __syncthreads();                             // panel and parameters are in LDS
                 pstamp(1);
             }
@@ -148,8 +163,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // sums, var = E[v^2] - mean^2 loses nothing the 16-bit operands have not lost already), one
     // exchange through LDS.
     float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 4 * 256) + lane * 4;   // this lane's X32 slots
-    auto layer_norm = [&](auto residual_tag, const float* lnp, auto emit) {
+    char* xh = reinterpret_cast<char*>(a.X) + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 2 * 1024) + lane * 16;   // ... X16 slots
+    auto layer_norm = [&](auto residual_tag, auto xhalf_tag, const float* lnp, auto emit) {
         constexpr bool RES = decltype(residual_tag)::value;
+        constexpr bool XH = decltype(xhalf_tag)::value;
         constexpr int STAMP = RES ? 7 : 9;
         // the lane's parameter quads: in registers for all token blocks at hidden 256 (2 x 4 quads),
         // re-read from LDS per block at hidden 512 (they would take 192 registers)
@@ -168,20 +185,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 bv;
-                    if constexpr (KEEP) bv = bias4[rb][q]; else bv = quad(0, rb, q);
-                    if constexpr (RES) {     // X32 order: one contiguous KiB per load instruction
-                        const float4 rv = *reinterpret_cast<const float4*>(xt + ((t * RB + rb) * 4 + q) * 256);
-                        bv.x += rv.x; bv.y += rv.y; bv.z += rv.z; bv.w += rv.w;
-                    }
-                    yacc[rb][t][4 * q + 0] += bv.x; yacc[rb][t][4 * q + 1] += bv.y;
-                    yacc[rb][t][4 * q + 2] += bv.z; yacc[rb][t][4 * q + 3] += bv.w;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if constexpr (RES && XH) {          // X16 order: one contiguous KiB of fp16 per load instruction
+                        u32x4 rv;
+                        if constexpr (XPRE) rv = res[(t * RB + rb) * 2 + s2];          // (requested at the top of the kernel)
+                        else rv = *reinterpret_cast<const u32x4*>(xh + ((t * RB + rb) * 2 + s2) * 1024);
+                        const uint32_t w4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = yacc[rb][t][4 * q + r];
-                        sum += v;
-                        sq = fmaf(v, v, sq);
+                        for (int j = 0; j < 4; ++j) {
+                            const f16x2 pr = __builtin_bit_cast(f16x2, w4[j]);
+                            r8[2 * j] = (float)pr[0];
+                            r8[2 * j + 1] = (float)pr[1];
+                        }
+                    } else if constexpr (RES) {         // X32 order: one contiguous KiB per load instruction
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float4 rv = *reinterpret_cast<const float4*>(xt + ((t * RB + rb) * 4 + 2 * s2 + e) * 256);
+                            r8[4 * e + 0] = rv.x; r8[4 * e + 1] = rv.y; r8[4 * e + 2] = rv.z; r8[4 * e + 3] = rv.w;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int q = 2 * s2 + e;
+                        float4 bv;
+                        if constexpr (KEEP) bv = bias4[rb][q]; else bv = quad(0, rb, q);
+                        yacc[rb][t][4 * q + 0] += bv.x + r8[4 * e + 0]; yacc[rb][t][4 * q + 1] += bv.y + r8[4 * e + 1];
+                        yacc[rb][t][4 * q + 2] += bv.z + r8[4 * e + 2]; yacc[rb][t][4 * q + 3] += bv.w + r8[4 * e + 3];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = yacc[rb][t][4 * q + r];
+                            sum += v;
+                            sq = fmaf(v, v, sq);
+                        }
                     }
                 }
             sum = pair_sum(sum);
@@ -235,7 +271,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // LayerNorm-1: the panel holds x1 afterwards (every wave finished reading the attention
     // output a barrier ago), the accumulators keep x1 as the FFN's residual
-    layer_norm(std::true_type{}, lnp1, panel_write);
+    if (a.x_half) layer_norm(std::true_type{}, std::true_type{}, lnp1, panel_write);
+    else layer_norm(std::true_type{}, std::false_type{}, lnp1, panel_write);
     // W1 fragments of chunk 0 (image order [chunk][wave][ks]); nothing register-hungry follows before their wait
     load16(w1f, a.w1_img + ((size_t)wave * KS) * 1024);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -243,135 +280,187 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(3);
 
     // ---- FFN: per 128-hidden chunk  h = relu(W1c x1 + b1c)  (phase A),  y += W2c h  (phase B) ---
-    for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
+    // b1 of the lane's 16 hidden rows of chunk c -> the C operand of the chunk's first MFMAs
+    auto bias_read = [&](u32x4 (&braw)[4], int c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ds_read128<0>(braw[q], lds0 + G::L_B1 + (uint32_t)((c * HC + 32 * wave + 8 * q + 4 * hh) * 4));
+    };
+    auto bias_of = [&](u32x4 (&braw)[4]) {
+        f32x16 bias;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            asm volatile("" : "+v"(braw[q]));
+            bias[4 * q + 0] = __uint_as_float(braw[q].x); bias[4 * q + 1] = __uint_as_float(braw[q].y);
+            bias[4 * q + 2] = __uint_as_float(braw[q].z); bias[4 * q + 3] = __uint_as_float(braw[q].w);
+        }
+        return bias;
+    };
+    if constexpr (HIDT == 256) {
+        // ONE fragment stream per chunk, 120 steps / 160 MFMAs, nothing of the hand-over exposed:
+        //   steps   0.. 47  phase A, token blocks 0..2 (panel fragment (tb, ks), ks outer); this chunk's W2 fragments requested
+        //   steps  48.. 79  phase A, token blocks 3, 4; the h of blocks 0..2 packed and written between the MFMAs
+        //   step   74       barrier X: every wave's h of blocks 0..2 is in LDS (and every wave is out of the previous chunk)
+        //   steps  80..103  phase B, token blocks 0..2 (h fragment (tb, ks), two MFMAs per step); the h of blocks 3, 4
+        //                   written; the next chunk's W1 fragments and b1 requested
+        //   step   98       barrier Y: every wave's h of blocks 3, 4 is in LDS (and every wave has issued its reads of blocks 0..2)
+        //   steps 104..119  phase B, token blocks 3, 4
+        // The ring reads 6 fragments ahead: fragment 80 (the first of h) is requested after step 74's MFMA, fragment 104 after
+        // step 98's -- the barriers sit exactly there.  A wave's own ds_writes are complete at its barrier: LDS operations
+        // complete in order and the wave has since waited for ring reads it requested after them.  h of blocks 0..2 is
+        // overwritten 70 steps after barrier Y of the previous chunk, h of blocks 3, 4 after barrier X of this one.
+        u32x4 braw[4];
+        bias_read(braw, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
 #ifdef PPG_FFN_TIMING
-        auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
+            auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
 #else
-        auto cstamp = [&](int) {};
+            auto cstamp = [&](int) {};
 #endif
-        cstamp(0);
-        f32x16 bias;            // C operand of the chunk's first MFMAs: b1 of the lane's 16 hidden rows
-        {
-            u32x4 braw[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ds_read128<0>(braw[q], lds0 + G::L_B1 + (uint32_t)((c * HC + 32 * wave + 8 * q + 4 * hh) * 4));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                asm volatile("" : "+v"(braw[q]));
-                bias[4 * q + 0] = __uint_as_float(braw[q].x); bias[4 * q + 1] = __uint_as_float(braw[q].y);
-                bias[4 * q + 2] = __uint_as_float(braw[q].z); bias[4 * q + 3] = __uint_as_float(braw[q].w);
-            }
-        }
-        vm_wait_all(w1f);
-        const char* w1c = a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024;          // this chunk's W1 fragments [ks]
-        const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;      // this chunk's W2 fragments [rb][ks8]
-        // what goes into the W1 register set after this chunk: the next chunk's first 16 fragments; after the
-        // last chunk the first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
-        const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
-                            : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1c);
-        f32x16 hacc[TB];
-        // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
-        auto h_write = [&](auto t_tag, auto s_tag) {
-            constexpr int t = decltype(t_tag)::value, s2 = decltype(s_tag)::value;
-            const u32x4 frag = u32x4{P::relu2(P::pack2(hacc[t][8 * s2 + 0], hacc[t][8 * s2 + 1])), P::relu2(P::pack2(hacc[t][8 * s2 + 2], hacc[t][8 * s2 + 3])),
-                                     P::relu2(P::pack2(hacc[t][8 * s2 + 4], hacc[t][8 * s2 + 5])), P::relu2(P::pack2(hacc[t][8 * s2 + 6], hacc[t][8 * s2 + 7]))};
-            const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
-            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
-        };
-        if constexpr (HIDT == 256) {
-            // token blocks 0..2 first (48 steps), then 3..4 (32 steps) with the h of the first three packed
-            // and written between their MFMAs: only two blocks' worth of packing is left after the stream
-            stream<OffPanel<KS, 0, 0, 3>, 16 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / 3, tb = i % 3;
-                if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-                else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-                // this chunk's W2 fragments
-                if constexpr (i % 5 == 2) gload_frag<i / 5>(w2f[i / 5], voff, w2c);
-            });
-            cstamp(1);
-            stream<OffPanel<KS, 0, 3, 2>, 16 * 2, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / 2, tb = 3 + i % 2;
-                // (every wave is long done reading the previous chunk's h: the barrier costs its instruction)
-                if constexpr (i == 0) __builtin_amdgcn_s_barrier();
-                if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-                else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-                if constexpr (i % 5 == 2 && 10 + i / 5 < 16) gload_frag<10 + i / 5>(w2f[10 + i / 5], voff, w2c);
-                if constexpr (i % 5 == 1 && i / 5 < 6) h_write(std::integral_constant<int, (i / 5) / 2>{}, std::integral_constant<int, (i / 5) % 2>{});
-            });
-            cstamp(2);
-            h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-            h_write(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
-            h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{});
-            h_write(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            cstamp(3);
-            __syncthreads();
-            cstamp(4);
-            vm_wait_all(w2f);
-            stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / TB, tb = i % TB;
-                yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
-                yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
-                // the next chunk's W1 fragments, two loads per 10 MFMAs
-                if constexpr (tb == 1 || tb == 3) gload_frag<2 * ks + (tb == 3)>(w1f[2 * ks + (tb == 3)], voff, next1);
-            });
-        } else {
-            // hidden 512: 32 W1 and 32 W2 fragments per chunk pass through the two register sets in halves:
-            // A1 (W1 ks 0..15 in set 1) | A2 (ks 16..31 in set 2) | B1 (W2 row blocks 0, 1 in set 1) | B2 (2, 3 in set 2),
-            // each half prefetching the other set
-            stream<OffPanel<KS, 0, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / TB, tb = i % TB;
-                if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-                else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-                if constexpr (i % 3 == 1) gload_frag<16 + i / 3>(w2f[i / 3], voff, w1c);
-            });
-            vm_wait_all(w2f);
-            cstamp(1);
-            stream<OffPanel<KS, 16, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / TB, tb = i % TB;
-                if constexpr (i == 0) __builtin_amdgcn_s_barrier();        // the previous chunk's h is read
-                hacc[tb] = P::mma32(w2f[ks], bf, hacc[tb]);
-                if constexpr (i % 3 == 1) gload_frag<i / 3>(w1f[i / 3], voff, w2c);
-            });
-            cstamp(2);
-            [&]<int... U>(std::integer_sequence<int, U...>) {
-                (h_write(std::integral_constant<int, U / 2>{}, std::integral_constant<int, U % 2>{}), ...);
-            }(std::make_integer_sequence<int, 2 * TB>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            cstamp(3);
-            __syncthreads();
-            cstamp(4);
+            cstamp(0);
+            const f32x16 bias = bias_of(braw);
             vm_wait_all(w1f);
-            stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+            const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;      // this chunk's W2 fragments [rb][ks8]
+            // what goes into the W1 register set during phase B: the next chunk's fragments; after the last chunk the
+            // first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
+            const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
+                                : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024);
+            const int cn = c + 1 < NCH ? c + 1 : c;
+            f32x16 hacc[TB];
+            // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
+            auto h_write = [&](auto t_tag, auto s_tag) {
+                constexpr int t = decltype(t_tag)::value, s2 = decltype(s_tag)::value;
+                const u32x4 frag = u32x4{P::relu2(P::pack2(hacc[t][8 * s2 + 0], hacc[t][8 * s2 + 1])), P::relu2(P::pack2(hacc[t][8 * s2 + 2], hacc[t][8 * s2 + 3])),
+                                         P::relu2(P::pack2(hacc[t][8 * s2 + 4], hacc[t][8 * s2 + 5])), P::relu2(P::pack2(hacc[t][8 * s2 + 6], hacc[t][8 * s2 + 7]))};
+                const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
+                asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
+            };
+            stream<OffChunk256, 120, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / TB, tb = i % TB;
-                yacc[0][tb] = P::mma32(w1f[ks], bf, yacc[0][tb]);
-                yacc[1][tb] = P::mma32(w1f[8 + ks], bf, yacc[1][tb]);
-                if constexpr (i < 16) gload_frag<16 + i>(w2f[i], voff, w2c);
+                if constexpr (i < 48) {
+                    constexpr int ks = i / 3, tb = i % 3;
+                    if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+                    else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                    if constexpr (i % 3 == 1) gload_frag<i / 3>(w2f[i / 3], voff, w2c);
+                } else if constexpr (i < 80) {
+                    constexpr int j = i - 48, ks = j / 2, tb = 3 + j % 2;
+                    if constexpr (j == 0) cstamp(1);
+                    if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+                    else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                    if constexpr (j % 3 == 2 && j / 3 < 6) h_write(std::integral_constant<int, (j / 3) / 2>{}, std::integral_constant<int, (j / 3) % 2>{});
+                    if constexpr (i == 74) asm volatile("s_barrier" ::: "memory");
+                } else if constexpr (i < 104) {
+                    constexpr int j = i - 80, ks = j / 3, tb = j % 3;
+                    if constexpr (j == 0) { cstamp(2); vm_wait_all(w2f); }
+                    yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                    if constexpr (j < 16) gload_frag<j>(w1f[j], voff, next1);
+                    if constexpr (j % 2 == 1 && j / 2 < 4) h_write(std::integral_constant<int, 3 + (j / 2) / 2>{}, std::integral_constant<int, (j / 2) % 2>{});
+                    if constexpr (j == 17) bias_read(braw, cn);
+                    if constexpr (i == 98) asm volatile("s_barrier" ::: "memory");
+                } else {
+                    constexpr int j = i - 104, ks = j / 2, tb = 3 + j % 2;
+                    if constexpr (j == 0) cstamp(3);
+                    yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                }
             });
-            vm_wait_all(w2f);
-            stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int ks = i / TB, tb = i % TB;
-                yacc[2][tb] = P::mma32(w2f[ks], bf, yacc[2][tb]);
-                yacc[3][tb] = P::mma32(w2f[8 + ks], bf, yacc[3][tb]);
-                if constexpr (i < 16) gload_frag<i>(w1f[i], voff, next1);
-            });
+            cstamp(5);
         }
-        cstamp(5);
+    } else {
+        for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
+#ifdef PPG_FFN_TIMING
+            auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#else
+            auto cstamp = [&](int) {};
+#endif
+            cstamp(0);
+            f32x16 bias;            // C operand of the chunk's first MFMAs: b1 of the lane's 16 hidden rows
+            {
+                u32x4 braw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ds_read128<0>(braw[q], lds0 + G::L_B1 + (uint32_t)((c * HC + 32 * wave + 8 * q + 4 * hh) * 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    asm volatile("" : "+v"(braw[q]));
+                    bias[4 * q + 0] = __uint_as_float(braw[q].x); bias[4 * q + 1] = __uint_as_float(braw[q].y);
+                    bias[4 * q + 2] = __uint_as_float(braw[q].z); bias[4 * q + 3] = __uint_as_float(braw[q].w);
+                }
+            }
+            vm_wait_all(w1f);
+            const char* w1c = a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024;          // this chunk's W1 fragments [ks]
+            const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;      // this chunk's W2 fragments [rb][ks8]
+            // what goes into the W1 register set after this chunk: the next chunk's first 16 fragments; after the
+            // last chunk the first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
+            const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
+                                : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1c);
+            f32x16 hacc[TB];
+            // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
+            auto h_write = [&](auto t_tag, auto s_tag) {
+                constexpr int t = decltype(t_tag)::value, s2 = decltype(s_tag)::value;
+                const u32x4 frag = u32x4{P::relu2(P::pack2(hacc[t][8 * s2 + 0], hacc[t][8 * s2 + 1])), P::relu2(P::pack2(hacc[t][8 * s2 + 2], hacc[t][8 * s2 + 3])),
+                                         P::relu2(P::pack2(hacc[t][8 * s2 + 4], hacc[t][8 * s2 + 5])), P::relu2(P::pack2(hacc[t][8 * s2 + 6], hacc[t][8 * s2 + 7]))};
+                const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
+                asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
+            };
+                // hidden 512: 32 W1 and 32 W2 fragments per chunk pass through the two register sets in halves:
+                // A1 (W1 ks 0..15 in set 1) | A2 (ks 16..31 in set 2) | B1 (W2 row blocks 0, 1 in set 1) | B2 (2, 3 in set 2),
+                // each half prefetching the other set
+                stream<OffPanel<KS, 0, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / TB, tb = i % TB;
+                    if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
+                    else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                    if constexpr (i % 3 == 1) gload_frag<16 + i / 3>(w2f[i / 3], voff, w1c);
+                });
+                vm_wait_all(w2f);
+                cstamp(1);
+                stream<OffPanel<KS, 16, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / TB, tb = i % TB;
+                    if constexpr (i == 0) __builtin_amdgcn_s_barrier();        // the previous chunk's h is read
+                    hacc[tb] = P::mma32(w2f[ks], bf, hacc[tb]);
+                    if constexpr (i % 3 == 1) gload_frag<i / 3>(w1f[i / 3], voff, w2c);
+                });
+                cstamp(2);
+                [&]<int... U>(std::integer_sequence<int, U...>) {
+                    (h_write(std::integral_constant<int, U / 2>{}, std::integral_constant<int, U % 2>{}), ...);
+                }(std::make_integer_sequence<int, 2 * TB>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                cstamp(3);
+                __syncthreads();
+                cstamp(4);
+                vm_wait_all(w1f);
+                stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / TB, tb = i % TB;
+                    yacc[0][tb] = P::mma32(w1f[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(w1f[8 + ks], bf, yacc[1][tb]);
+                    if constexpr (i < 16) gload_frag<16 + i>(w2f[i], voff, w2c);
+                });
+                vm_wait_all(w2f);
+                stream<OffH<TB>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / TB, tb = i % TB;
+                    yacc[2][tb] = P::mma32(w2f[ks], bf, yacc[2][tb]);
+                    yacc[3][tb] = P::mma32(w2f[8 + ks], bf, yacc[3][tb]);
+                    if constexpr (i < 16) gload_frag<i>(w1f[i], voff, next1);
+                });
+            cstamp(5);
+        }
     }
     vm_wait_all(w1f);
     pstamp(4);
 
     // ---- LayerNorm-2 -> X (fp32 residual stream, X32 order: one KiB per store) and its row-major 16-bit copy
-    layer_norm(std::false_type{}, lnp2, [&](int t, int rb, const f32x16& y) {
-        if (a.write_x) {                                    // (the last layer's residual stream has no reader)
+    layer_norm(std::false_type{}, std::false_type{}, lnp2, [&](int t, int rb, const f32x16& y) {
+        if (a.write_x && a.x_half) {                        // (the last layer's residual stream has no reader)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                *reinterpret_cast<u32x4*>(xh + ((t * RB + rb) * 2 + s2) * 1024) = u32x4{pack_f16x2(y[8 * s2 + 0], y[8 * s2 + 1]), pack_f16x2(y[8 * s2 + 2], y[8 * s2 + 3]),
+                                                                                  pack_f16x2(y[8 * s2 + 4], y[8 * s2 + 5]), pack_f16x2(y[8 * s2 + 6], y[8 * s2 + 7])};
+        } else if (a.write_x) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<float4*>(xt + ((t * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);

@@ -636,6 +636,7 @@ class LongStream:
         self.stride = self.chunk - 2 * self.overlap
         self.received = 0
         self._windows = {}          # index -> [Stream, rows emitted so far]
+        self._done = -1             # windows <= this index have emitted all their kept rows (they finish in order)
         self._first = None
 
     def _window(self, index):
@@ -668,7 +669,9 @@ class LongStream:
         if n:
             first_window = max((lo + self.overlap - (self.chunk - 1) + self.stride - 1) // self.stride, 0)
             last_window = (hi - 1 + self.overlap) // self.stride
-            for index in range(first_window, last_window + 1):
+            for index in range(max(first_window, self._done + 1), last_window + 1):
+                # (a finished window's last `overlap` rows keep arriving: nobody keeps them, and feeding them
+                # would re-create its Stream -- workspace, K/V caches, a device synchronisation -- for nothing)
                 # window rows tt = f - stride * index + overlap in [0, chunk)
                 f0 = max(lo, self.stride * index - self.overlap)
                 f1 = min(hi, self.stride * index - self.overlap + self.chunk)
@@ -687,10 +690,12 @@ class LongStream:
                 if self.stride * index < total:   # a window whose kept rows start past the end does not exist
                     pieces.append(self._emit(index, stream.push(None, flush=True, softmax=softmax), total))
             self._windows.clear()
+            self._done = (self.received + self.overlap - 1) // self.stride if self.received else -1
         else:
             # windows that have emitted all their kept rows are done
             for index in [i for i, entry in self._windows.items() if entry[1] >= self.chunk - self.overlap]:
                 del self._windows[index]
+                self._done = max(self._done, index)
         if not pieces:
             return torch.empty(engine.output_channels, 0, dtype=torch.float32, device=engine.device)
         return torch.cat(pieces, dim=1)
@@ -777,6 +782,21 @@ class W2v2FeatureEncoder:
         return out
 
 
+def _weight_normed(conv, dim=2):
+    """The effective weight of a weight-normalised convolution (HF's positional convolution:
+    weight_norm(name='weight', dim=2)), computed from g and v -- with the legacy
+    torch.nn.utils.weight_norm `.weight` is a plain attribute that only the forward pre-hook
+    refreshes, so after from_pretrained it can be stale."""
+    parametrizations = getattr(conv, 'parametrizations', None)
+    if parametrizations is not None and 'weight' in parametrizations:
+        g, v = parametrizations.weight.original0, parametrizations.weight.original1
+    elif hasattr(conv, 'weight_g') and hasattr(conv, 'weight_v'):
+        g, v = conv.weight_g, conv.weight_v
+    else:
+        return conv.weight
+    return torch._weight_norm(v.detach().float(), g.detach().float(), dim)
+
+
 class W2v2Body:
     """The wav2vec 2.0 transformer body on the HIP engine (ppg_w2v2_body_*): HF
     ``Wav2Vec2Model``'s ``feature_projection`` + ``encoder`` (post-norm layers, grouped
@@ -804,7 +824,7 @@ class W2v2Body:
         wts.proj_norm_weight, wts.proj_norm_bias = ptr(projection.layer_norm.weight), ptr(projection.layer_norm.bias)
         wts.proj_weight, wts.proj_bias = ptr(projection.projection.weight), ptr(projection.projection.bias)
         conv = encoder.pos_conv_embed.conv
-        wts.pos_conv_weight, wts.pos_conv_bias = ptr(conv.weight), ptr(conv.bias)      # .weight: weight norm applied
+        wts.pos_conv_weight, wts.pos_conv_bias = ptr(_weight_normed(conv)), ptr(conv.bias)
         wts.enc_norm_weight, wts.enc_norm_bias = ptr(encoder.layer_norm.weight), ptr(encoder.layer_norm.bias)
         for index, layer in enumerate(encoder.layers):
             lw, attn = wts.layers[index], layer.attention

@@ -17,31 +17,44 @@ _HUB_FILES = {'mel': 'mel-800k.pt', 'w2v2fb': 'w2v2fb-425k.pt'}
 def _decode_other(file):
     """Containers the native RIFF/WAV reader does not handle (the reference
     decodes mp3 / flac / ogg through torchaudio.load, ppgs/load.py:17-30): use
-    soundfile or torchaudio when one of them is installed."""
+    soundfile, then torchaudio, whichever is installed AND can decode the file
+    (an old libsndfile raises LibsndfileError -- a RuntimeError -- on mp3).
+    A file nobody can decode is a ValueError, which the file pipelines turn
+    into "skipped with a warning" instead of the end of the job."""
+    failures = []
     try:
         import soundfile
-        data, sample_rate = soundfile.read(os.fspath(file), dtype='float32', always_2d=True)
-        return torch.from_numpy(np.ascontiguousarray(data.T)), int(sample_rate)
+        try:
+            data, sample_rate = soundfile.read(os.fspath(file), dtype='float32', always_2d=True)
+            return torch.from_numpy(np.ascontiguousarray(data.T)), int(sample_rate)
+        except (RuntimeError, OSError, ValueError) as error:
+            failures.append(f'soundfile: {error}')
     except ImportError:
-        pass
+        failures.append('soundfile: not installed')
     try:
         import torchaudio
-        samples, sample_rate = torchaudio.load(os.fspath(file))
-        return samples.to(torch.float32), int(sample_rate)
+        try:
+            samples, sample_rate = torchaudio.load(os.fspath(file))
+            return samples.to(torch.float32), int(sample_rate)
+        except (RuntimeError, OSError, ValueError) as error:
+            failures.append(f'torchaudio: {error}')
     except ImportError:
-        raise ValueError(
-            f'{file}: not a RIFF/WAV file, and neither soundfile nor torchaudio '
-            'is installed to decode other containers') from None
+        failures.append('torchaudio: not installed')
+    raise ValueError(f'{file}: not a RIFF/WAV file and no decoder for it ({"; ".join(failures)})')
 
 
 def _is_riff(file):
     with open(os.fspath(file), 'rb') as handle:
         head = handle.read(12)
-    return len(head) == 12 and head[:4] in (b'RIFF', b'RIFX') and head[8:12] == b'WAVE'
+    # (big-endian RIFX is not something the native reader parses: it goes to the other decoders)
+    return len(head) == 12 and head[:4] == b'RIFF' and head[8:12] == b'WAVE'
 
 
-def audio(file):
+def audio(file, gpu=None):
     """Load an audio file as (channels, samples) fp32 at 16 kHz.
+
+    A file at another sample rate is converted by the HIP resampler on device
+    `gpu` (default: the current HIP device) -- it needs one; 16 kHz files do not.
 
     The reference goes through torchaudio.load + Resample
     (ppgs/load.py:17-30); here PCM/float WAV is decoded directly, other
@@ -51,7 +64,7 @@ def audio(file):
     from . import core
     if not _is_riff(file):
         samples, sample_rate = _decode_other(file)
-        return core.resample(samples, sample_rate)
+        return core.resample(samples, sample_rate, gpu=gpu)
     from scipy.io import wavfile
     sample_rate, data = wavfile.read(os.fspath(file))
     if data.dtype == np.uint8:
@@ -65,7 +78,7 @@ def audio(file):
         samples = samples[None]
     else:
         samples = samples.T.contiguous()       # (channels, samples)
-    return core.resample(samples, sample_rate)
+    return core.resample(samples, sample_rate, gpu=gpu)
 
 
 def info(file):

@@ -1009,13 +1009,14 @@ def test_w2v2_body_shapes_vs_hf_modules():
             assert (out[item, :count] - ref[item, :count]).abs().max() < 1e-4, (shape, item)
 
 
-@pytest.mark.parametrize('total', [1130, 780, 501])
+@pytest.mark.parametrize('total', [1130, 780, 501, 2470])
 def test_long_stream_equals_chunked_causal_forward(total):
     """An utterance longer than a window, streamed (engine.long_stream: every frame goes to the one
     or two 500-row windows of the reference's chunk rule it belongs to, each a KV-cached stream)
     equals the reference's chunked causal forward (oracle), frame by frame.  1130 frames = three
     windows; 780 = two, with a third that starts inside the utterance but past its kept range;
-    501 = the shortest chunked case."""
+    501 = the shortest chunked case; 2470 = seven windows (the live-window bound below is what
+    keeps a long-running stream's device memory constant)."""
     engine, state = eng(causal=True)
     gen = torch.Generator().manual_seed(55)
     feats = torch.randn(80, total, generator=gen).half()
@@ -1030,6 +1031,8 @@ def test_long_stream_equals_chunked_causal_forward(total):
         received += n
         index += 1
         assert sum(p.shape[1] for p in pieces) <= max(received - 4, 0)
+        # a finished window is never fed (and so never re-created) again: at most two are ever alive
+        assert len(stream._windows) <= 2
     pieces.append(stream.push(None, flush=True))
     out = torch.cat(pieces, dim=1).cpu().numpy()
     assert out.shape == (40, total)
