@@ -206,10 +206,12 @@ def run_c2(args, rank, world, local_rank, use_dist):
         mel = ppgs_amd.preprocess.mel.from_audios(audio)
         return engine.encode(mel, lengths)
 
+    nccl = use_dist and dist.get_backend() == 'nccl'
+
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if nccl else dist.barrier()
             torch.cuda.synchronize()
 
     def timed_block(engine=model):
@@ -220,7 +222,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
         barrier()
         elapsed = time.perf_counter() - start
         if use_dist:
-            worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+            worst = torch.tensor([elapsed], device='cuda' if nccl else 'cpu', dtype=torch.float64)
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)
             elapsed = float(worst.item())
         return elapsed, out
@@ -429,10 +431,12 @@ def run_c4(args, rank, world, local_rank, use_dist):
                 outs.append(torch.cat([out[row, :, :n].T for row, n in enumerate(lens)], dim=0))
         return outs
 
+    nccl = use_dist and dist.get_backend() == 'nccl'
+
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if nccl else dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -447,7 +451,7 @@ def run_c4(args, rank, world, local_rank, use_dist):
     ffn_ms, ffn_launches = model.profile_read()['ffn']
     model.profile(False)
     if use_dist:
-        worst = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        worst = torch.tensor([elapsed], device='cuda' if nccl else 'cpu', dtype=torch.float64)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         elapsed = float(worst.item())
     # the only collective of the path: gatherv of the posteriors to rank 0
@@ -519,21 +523,38 @@ def rank_main(args):
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
     if args.gpus != world:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)')
+    # PPGS_BENCH_ALIAS_GPUS=1: a DRY RUN of the N-rank path on fewer GPUs than ranks -- rank r uses GPU
+    # r mod (GPUs present).  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the process
+    # group is gloo and the gatherv is staged through host memory: what such a run checks is the N-process
+    # host side (sharding, per-rank shards only, CPU binding, N launch loops sharing a GPU, the gatherv's
+    # bookkeeping); its frames/s say nothing about N GPUs and the record is labelled so.
+    alias = bool(os.environ.get('PPGS_BENCH_ALIAS_GPUS')) and torch.cuda.device_count() < world
+    if alias:
+        local_rank = local_rank % torch.cuda.device_count()
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f'bench.py: rank {rank} wants GPU {local_rank}, the node shows {torch.cuda.device_count()}')
     torch.cuda.set_device(local_rank)
     # (PPGS_BENCH_FORCE_DIST=1: exercise the RCCL barrier / max-over-ranks / gather path with one rank)
     use_dist = world > 1 or bool(os.environ.get('PPGS_BENCH_FORCE_DIST'))
+    cpus = []
+    if world > 1:
+        from ppgs_amd import distributed
+        cpus = distributed.bind_cpus(int(os.environ.get('LOCAL_RANK', '0')), world, device=local_rank if alias else None)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if alias:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
     line = None
     try:
         line = (run_c2 if args.workload == 'c2' else run_c4)(args, rank, world, local_rank, use_dist)
         if rank == 0 and use_dist:
-            line['rccl_world_size'] = dist.get_world_size()
+            line['backend'] = 'gloo: PPGS_BENCH_ALIAS_GPUS dry run, ranks share GPUs -- NOT a multi-GPU measurement' if alias else 'nccl (RCCL)'
+            line['rccl_world_size' if not alias else 'gloo_world_size'] = dist.get_world_size()
+            line['rank0_cpus'] = len(cpus)
     finally:
         if use_dist:
             dist.destroy_process_group()
@@ -557,9 +578,10 @@ def main():
         rank_main(args)                  # launched by torch.distributed.run (or a single rank)
         return
     # bare `python bench.py --gpus N`: spawn the N ranks here
-    if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
-        found = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        raise SystemExit(f'bench.py: --gpus {args.gpus} but this node shows {found} GPU(s)')
+    found = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if found < args.gpus and not (found and os.environ.get('PPGS_BENCH_ALIAS_GPUS')):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but this node shows {found} GPU(s) '
+                         '(PPGS_BENCH_ALIAS_GPUS=1: dry run of the N-rank host path on the GPUs present, over gloo)')
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sock:

@@ -269,6 +269,7 @@ struct PpgEngine {
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
+    bool subtile = true;     // layer32 path, hidden 256: workgroups of two token blocks (three per 160-token tile) when whole tiles would leave two thirds of the CUs idle (PPGS_AMD_SUBTILE=0: whole tiles always)
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
@@ -882,6 +883,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_SUBTILE")) e->subtile = atoi(v) != 0;
     e->x16 = cfg->precision == PPG_PRECISION_BF16;
     if (const char* v = getenv("PPGS_AMD_X16")) e->x16 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_OUTCONV")) e->outconv = atoi(v) != 0;
@@ -1171,7 +1173,10 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
 
     const bool use32 = e->layer32 && e->ffn_fused && ws.ffn_splits == 1;
     // (one 160-token tile per workgroup: below half a chip of tiles the three launches, with their smaller workgroups, are as fast)
-    const bool head = use32 && e->head32 && 2 * ((M + ppg::layer32_tokens(H) - 1) / ppg::layer32_tokens(H)) >= e->num_cus;
+    const int tiles32 = (M + ppg::layer32_tokens(H) - 1) / ppg::layer32_tokens(H);
+    // sub-tile workgroups (two token blocks, three per tile) when whole tiles would leave two thirds of the CUs idle
+    const bool sub32 = use32 && e->subtile && H == 256 && (F / 128) % 2 == 0 && 3 * tiles32 <= e->num_cus;
+    const bool head = use32 && e->head32 && (2 * tiles32 >= e->num_cus || sub32);
     if (head) {
         Timed t(e, PPG_K_INCONV, s);
         Head32Args a{};
@@ -1184,6 +1189,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.qk_slack = qk + (size_t)M * 2 * H * e->sz; a.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
         a.debug_mode = e->h32_debug;
         a.x_half = e->x16;
+        a.sub_tiles = sub32;
         a.dbg = e->head_dbg;
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
@@ -1247,6 +1253,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.X = X; a.Xb = Xb; a.M = M; a.F = F; a.H = H; a.dbg = l == 0 ? e->ffn_dbg : nullptr;
             a.debug_mode = e->l32_debug;
             a.x_half = e->x16;
+            a.sub_tiles = sub32;
             qkv_done = e->qkv_fused && l + 1 < c.num_layers;
             a.write_x = l + 1 < c.num_layers;
             if (qkv_done) {

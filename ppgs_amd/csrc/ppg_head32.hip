@@ -33,19 +33,24 @@ struct OffIn {
     }
 };
 
-template <class P>
+template <class P, int TBS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void head32_kernel(Head32Args a) {
-    using G = Geo<HID>;
+    using G = Geo<HID, TBS>;
     constexpr int RB = G::RB, KS = G::KS, TB = G::TBN, TOKS = G::TOKS;
+    // sub-tile workgroups (TBS = 2: three per 160-token tile, as in ppg_layer32.hip): workgroup b takes token blocks
+    // tb0 .. of tile b / NSUB; a block past the tile's end is the next tile's first rows, computed and not stored
+    constexpr int TBT = tile_blocks(HID);
+    constexpr bool SUB = TBS != TBT;
+    constexpr int NSUB = (TBT + TBS - 1) / TBS;
     static_assert(RB == 2 && KSI % 2 == 0, "two row blocks per wave, two register sets");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= a.tiles) {
+    if ((int)blockIdx.x >= a.tiles * NSUB) {
         // scratch areas: the absent half of a window's last 32-column V^T group (columns are permuted inside a group:
         // position 8 g + 4 e + r for token 16 e + 4 g + r, so the absent 16 tokens are the pieces 8 g + 4 .. + 7; the
         // present half is written by the tiles, byte-disjoint), the slack behind the last V^T column, the q | k rows
         // behind the last token
-        for (int job = blockIdx.x - a.tiles; job <= a.nwin + 1; job += gridDim.x - a.tiles) {
+        for (int job = blockIdx.x - a.tiles * NSUB; job <= a.nwin + 1; job += gridDim.x - a.tiles * NSUB) {
             if (job == a.nwin + 1) {
                 for (int i = tid; i < a.qk_slack_bytes / 16; i += 256) reinterpret_cast<uint4*>(a.qk_slack)[i] = make_uint4(0u, 0u, 0u, 0u);
             } else if (job == a.nwin) {
@@ -71,7 +76,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * TOKS;
+    const int tile = SUB ? (int)blockIdx.x / NSUB : (int)blockIdx.x;
+    const int tb0 = SUB ? ((int)blockIdx.x % NSUB) * TBS : 0;
+    const int nblk = SUB ? min(TBS, TBT - tb0) : TBS;
+    const int m0 = tile * (32 * TBT) + 32 * tb0;
     const uint32_t lds0 = lds_addr32(smem);
     const uint32_t voff = lane * 16;
     const uint32_t pb0 = lds0 + G::L_ACT + lane * 16;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* bq_lds = reinterpret_cast<float*>(smem + G::L_BQ);
 
     auto pstamp = [&](int k) {
-        if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 16 + k] = __builtin_amdgcn_s_memtime();
+        if (!SUB && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 16 + k] = __builtin_amdgcn_s_memtime();
     };
     pstamp(0);
     u32x4 w1f[16], w2f[16];
@@ -200,8 +208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     pstamp(4);
     // ---- 3. x = live ? PE[tt] + (valid ? y + bias : 0) : 0 (as linear_kernel<EPI_INCONV>) -> X32 and the panel
-    float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 4 * 256) + lane * 4;
-    char* xh = reinterpret_cast<char*>(a.X) + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 2 * 1024) + lane * 16;   // X16 order
+    float* xt = a.X + ((size_t)tile * 4 + wave) * (TBT * RB * 4 * 256) + lane * 4;
+    char* xh = reinterpret_cast<char*>(a.X) + ((size_t)tile * 4 + wave) * (TBT * RB * 2 * 1024) + lane * 16;   // X16 order
     auto emit = [&](auto rb_tag) {
         constexpr int rb = decltype(rb_tag)::value;
         const int f0 = fbase + 32 * rb + 16 * hh;            // the lane's 16 consecutive features of the block
@@ -222,16 +230,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 y[4 * q + 1] = live[t] ? pv[t][q].y + (valid[t] ? yacc[rb][t][4 * q + 1] + bias[q].y : 0.f) : 0.f;
                 y[4 * q + 2] = live[t] ? pv[t][q].z + (valid[t] ? yacc[rb][t][4 * q + 2] + bias[q].z : 0.f) : 0.f;
                 y[4 * q + 3] = live[t] ? pv[t][q].w + (valid[t] ? yacc[rb][t][4 * q + 3] + bias[q].w : 0.f) : 0.f;
-                if (!a.x_half)
-                    *reinterpret_cast<float4*>(xt + ((t * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                if (!a.x_half && t < nblk)
+                    *reinterpret_cast<float4*>(xt + (((tb0 + t) * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
             }
-            if (a.x_half) {
+            if (a.x_half && t < nblk) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    *reinterpret_cast<u32x4*>(xh + ((t * RB + rb) * 2 + s2) * 1024) = u32x4{pack_f16x2(y[8 * s2 + 0], y[8 * s2 + 1]), pack_f16x2(y[8 * s2 + 2], y[8 * s2 + 3]),
+                    *reinterpret_cast<u32x4*>(xh + (((tb0 + t) * RB + rb) * 2 + s2) * 1024) = u32x4{pack_f16x2(y[8 * s2 + 0], y[8 * s2 + 1]), pack_f16x2(y[8 * s2 + 2], y[8 * s2 + 3]),
                                                                                       pack_f16x2(y[8 * s2 + 4], y[8 * s2 + 5]), pack_f16x2(y[8 * s2 + 6], y[8 * s2 + 7])};
             }
-            panel_store<P, HID>(pb0, wave, t, rb, y);
+            panel_store<P, HID, TBS>(pb0, wave, t, rb, y);
         }
     };
     emit(std::integral_constant<int, 0>{});
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Layer32Args la{};
     la.wq_img = a.wq_img; la.qk_out = a.qk_out; la.vt_out = a.vt_out; la.vt_ld = a.vt_ld;
     la.blk_win = a.blk_win; la.win = a.win; la.M = a.M; la.H = HID;
-    if (!(a.debug_mode & 2)) qkv_tail<P, HID>(la, smem, m0, w1f, w2f);
+    if (!(a.debug_mode & 2)) qkv_tail<P, HID, TBS>(la, smem, m0, w1f, w2f, nblk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pstamp(7);
 }
@@ -257,19 +265,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 namespace ppg {
 
 hipError_t launch_head32(int precision, const Head32Args& a, hipStream_t s) {
-    using G = Geo<HID>;
-    if (a.H != HID || a.C > CP || a.M <= 0 || a.tiles != (a.M + G::TOKS - 1) / G::TOKS) return hipErrorInvalidValue;
-    const size_t lds = G::L_B1;
-    const dim3 grid(a.tiles + std::min(a.nwin + 2, 32));
-    auto launch = [&](auto kern) {
+    if (a.H != HID || a.C > CP || a.M <= 0 || a.tiles != (a.M + 32 * tile_blocks(HID) - 1) / (32 * tile_blocks(HID))) return hipErrorInvalidValue;
+    auto launch = [&](auto kern, auto geo, int subs) {
+        using G = decltype(geo);
+        const size_t lds = G::L_B1;
+        const dim3 grid(a.tiles * subs + std::min(a.nwin + 2, 32));
         static ppg::LdsLimit limit;
         const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
         return hipGetLastError();
     };
-    if (precision == PPG_PRECISION_BF16) return launch(head32_kernel<PrecBF16>);
-    if (precision == PPG_PRECISION_FP16) return launch(head32_kernel<PrecF16>);
+    constexpr int T5 = tile_blocks(HID);
+    if (precision == PPG_PRECISION_BF16) return a.sub_tiles ? launch(head32_kernel<PrecBF16, 2>, Geo<HID, 2>{}, 3) : launch(head32_kernel<PrecBF16, T5>, Geo<HID>{}, 1);
+    if (precision == PPG_PRECISION_FP16) return a.sub_tiles ? launch(head32_kernel<PrecF16, 2>, Geo<HID, 2>{}, 3) : launch(head32_kernel<PrecF16, T5>, Geo<HID>{}, 1);
     return hipErrorInvalidValue;
 }
 

@@ -17,18 +17,23 @@ constexpr int HC = 128;               // hidden rows of the FFN per chunk (4 wav
 // Geometry of a hidden width: wave w owns features 32 RB w .. + 32 RB - 1 (RB 32-row blocks)
 // of every HIDT-wide result; the workgroup's TBN token blocks of 32 keep the accumulators
 // (RB * TBN + TBN blocks of 16 registers) inside the 256 AGPRs.
-template <int HIDT>
+// A workgroup's TBN may be smaller than the tile's (sub-tile workgroups, hidden 256 with TBN = 2: batches that
+// cannot give every CU a tile of 5 token blocks): the memory orders X32 / X16 / AO32 stay those of the full tile
+// (tile_blocks(HIDT) token blocks), the workgroup takes TBN consecutive blocks of one.
+constexpr int tile_blocks(int hidt) { return hidt == 256 ? 5 : 3; }
+template <int HIDT, int TBN_ = tile_blocks(HIDT)>
 struct Geo {
     static_assert(HIDT == 256 || HIDT == 512, "hidden width");
     static constexpr int RB = HIDT / 128;
     static constexpr int KS = HIDT / 16;            // 16-wide K-steps of a token-panel row
     static constexpr int KH = KS / 16;              // halves of 16 K-steps (one register set of fragments each)
-    static constexpr int TBN = HIDT == 256 ? 5 : 3;
+    static constexpr int TBN = TBN_;
     static constexpr int TOKS = 32 * TBN;
+    static constexpr int HBUFS = TBN_ == tile_blocks(HIDT) ? 1 : 2;    // sub-tile workgroups double-buffer h
     // LDS map (bytes)
     static constexpr int L_ACT = 0;                             // token panel: fragments [tb][KS] of 1 KiB
-    static constexpr int L_H = TBN * KS * 1024;                 // h of one chunk: fragments [tb][8]
-    static constexpr int L_LNP1 = L_H + TBN * 8 * 1024;         // [bo | gamma1 | beta1]
+    static constexpr int L_H = TBN * KS * 1024;                 // h of one chunk: fragments [tb][8] (x HBUFS)
+    static constexpr int L_LNP1 = L_H + HBUFS * TBN * 8 * 1024; // [bo | gamma1 | beta1]
     static constexpr int L_LNP2 = L_LNP1 + 3 * HIDT * 4;        // [b2 | gamma2 | beta2]
     static constexpr int L_BQ = L_LNP2 + 3 * HIDT * 4;          // next layer's in_proj bias
     static constexpr int L_STATS = L_BQ + 3 * HIDT * 4;         // LayerNorm partial sums [2][4 waves][TOKS]
@@ -114,6 +119,10 @@ struct OffPanel { static constexpr int at(int i) { return ((TB0 + i % NTB) * KS 
 template <int TBN>
 struct OffH { static constexpr int at(int i) { return ((i % TBN) * 8 + i / TBN) * 1024; } };
 
+// h stream of a sub-tile workgroup: buffer PAR of two
+template <int TBN, int PAR>
+struct OffH2 { static constexpr int at(int i) { return PAR * (TBN * 8 * 1024) + ((i % TBN) * 8 + i / TBN) * 1024; } };
+
 // The hidden-256 layer kernel's FFN chunk as ONE stream (see ppg_layer32.hip): steps 0..47 phase A on token blocks
 // 0..2 (panel fragment (tb, ks), ks outer), 48..79 phase A on blocks 3, 4, 80..103 phase B on blocks 0..2 (h fragment
 // (tb, ks), ks outer), 104..119 phase B on blocks 3, 4; offsets from the panel base (h lies behind the panel)
@@ -134,9 +143,9 @@ __device__ __forceinline__ float pair_sum(float v) {          // lanes l and l +
 
 // The 16 results of block (t, rb) of this wave, packed, into the token panel: K-steps 2 RB w + 2 rb, + 1
 // (slot 4e + r of K-step s' = register 4 (2s' + e) + r = natural feature 32 (ks/2) + 16 hh + 8 (ks%2) + 4e + r)
-template <class P, int HIDT>
+template <class P, int HIDT, int TBS = tile_blocks(HIDT)>
 __device__ __forceinline__ void panel_store(uint32_t pb0, int wave, int t, int rb, const f32x16& y) {
-    using G = Geo<HIDT>;
+    using G = Geo<HIDT, TBS>;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const u32x4 frag = u32x4{P::pack2(y[8 * s + 0], y[8 * s + 1]), P::pack2(y[8 * s + 2], y[8 * s + 3]),
@@ -162,9 +171,10 @@ __device__ __forceinline__ void panel_store(uint32_t pb0, int wave, int t, int r
 // step, on top of 1.4 - 3.2 k cycles of epilogue with the matrix pipe idle).  The count is exact only in a tile
 // whose rows all exist and whose token blocks are whole 32-token groups of V^T (`regular`: every tile of a
 // batch of 32-aligned windows); any other tile waits with vmcnt(0).
-template <class P, int HIDT>
-__device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const int m0, u32x4 (&w1f)[16], u32x4 (&w2f)[16]) {
-    using G = Geo<HIDT>;
+template <class P, int HIDT, int TBS = tile_blocks(HIDT)>
+__device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const int m0, u32x4 (&w1f)[16], u32x4 (&w2f)[16],
+                                         const int nblk = TBS) {
+    using G = Geo<HIDT, TBS>;
     constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
     constexpr int NSTEP = 3 * RB, NHS = NSTEP * KH;
     constexpr int NMMA = 16 * TB;                           // MFMAs (= stream steps) of a half-step
@@ -183,14 +193,14 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
     // transposed-V columns of the wave-uniform 16-token halves of every token block
     int vcol[TB][2];
     bool valigned[TB];
-    bool regular = m0 + TOKS <= a.M;
+    bool regular = m0 + TOKS <= a.M && nblk == TB;
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int mb = m0 + 32 * t + 16 * h;
             vcol[t][h] = -1;
-            if (mb < a.M) {
+            if (mb < a.M && t < nblk) {           // (t >= nblk: a token block past the end of a sub-tile workgroup's tile)
                 const int w = a.blk_win[mb >> 4];
                 if (w >= 0) {
                     const int ttb = mb - a.win[w].tok_off;
@@ -222,7 +232,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         if constexpr (KIND < 2) {
             // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh + 8 s2 .. + 7
             const int m = m0 + 32 * t + tok;
-            if (m < a.M) {
+            if (m < a.M && t < nblk) {
                 char* dst = a.qk_out + ((size_t)m * 2 * HIDT + HIDT * KIND + 32 * RBI + fbase + 16 * hh) * 2;
                 const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
                 *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{

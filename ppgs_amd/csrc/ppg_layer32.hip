@@ -32,16 +32,27 @@
 
 namespace {
 
-template <class P, int HIDT, bool QKV>
+template <class P, int HIDT, bool QKV, int TBS = tile_blocks(HIDT)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void layer32_kernel(Layer32Args a) {
-    using G = Geo<HIDT>;
+    using G = Geo<HIDT, TBS>;
     constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
+    // Sub-tile workgroups (TBS < the tile's token blocks): workgroup b takes blocks tb0 .. tb0 + nblk - 1 of tile
+    // b / NSUB; X32 / X16 / AO32 keep the full tile's order.  A block past the tile's end (the last sub-tile of a
+    // 5-block tile split 2 + 2 + 1) is computed on the tile's block 0 again and never stored.
+    constexpr int TBT = tile_blocks(HIDT);
+    constexpr bool SUB = TBS != TBT;
+    constexpr int NSUB = (TBT + TBS - 1) / TBS;
+    static_assert(!SUB || (HIDT == 256 && TBS == 2), "sub-tile workgroups: hidden 256, two token blocks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * TOKS;
+    const int tile = SUB ? (int)blockIdx.x / NSUB : (int)blockIdx.x;
+    const int tb0 = SUB ? ((int)blockIdx.x % NSUB) * TBS : 0;
+    const int nblk = SUB ? min(TBS, TBT - tb0) : TBS;
+    auto gblock = [&](int t) { return SUB ? tb0 + (t < nblk ? t : -tb0) : t; };      // the tile's block behind local block t
+    const int m0 = tile * (32 * TBT) + 32 * tb0;
     const int NCH = a.F / HC;
     const uint32_t lds0 = lds_addr32(smem);
     const uint32_t voff = lane * 16;
@@ -76,16 +87,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     u32x4 res[NRES];
     const bool xpre = XPRE && a.x_half;
     if (xpre) {
-        const char* xbase = reinterpret_cast<const char*>(a.X) + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 2 * 1024);
-        [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(res[K], voff, xbase), ...); }(std::make_integer_sequence<int, NRES>{});
+        const char* xbase = reinterpret_cast<const char*>(a.X) + ((size_t)tile * 4 + wave) * (TBT * RB * 2 * 1024);
+        if constexpr (!SUB) {
+            [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(res[K], voff, xbase), ...); }(std::make_integer_sequence<int, NRES>{});
+        } else {
+            [&]<int... K>(std::integer_sequence<int, K...>) {
+                (gload_frag<K % (RB * 2)>(res[K], voff, xbase + (size_t)gblock(K / (RB * 2)) * (RB * 2 * 1024)), ...);
+            }(std::make_integer_sequence<int, NRES>{});
+        }
     }
     // ---- attention output (AO32 order: this tile's fragments are one contiguous block) -> LDS panel
     {
-        const char* tile = a.ao + (size_t)blockIdx.x * (TB * KS * 1024);
+        const char* src = a.ao + (size_t)tile * (TBT * KS * 1024);
 #pragma unroll
         for (int i = 0; i < TB * KS / 4; ++i) {
-            const int p = 4 * i + wave;
-            glds16(tile + (size_t)p * 1024, voff, lds0 + G::L_ACT + p * 1024);
+            const int p = 4 * i + wave;               // fragment (local block p / KS, K-step p % KS)
+            const int q = SUB ? gblock(p / KS) * KS + p % KS : p;
+            glds16(src + (size_t)q * 1024, voff, lds0 + G::L_ACT + p * 1024);
         }
     }
     f32x16 yacc[RB][TB];
@@ -162,8 +180,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // One pass for the statistics (sum and sum of squares in fp32: the inputs are O(1) residual
     // sums, var = E[v^2] - mean^2 loses nothing the 16-bit operands have not lost already), one
     // exchange through LDS.
-    float* xt = a.X + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 4 * 256) + lane * 4;   // this lane's X32 slots
-    char* xh = reinterpret_cast<char*>(a.X) + ((size_t)blockIdx.x * 4 + wave) * (TB * RB * 2 * 1024) + lane * 16;   // ... X16 slots
+    float* xt = a.X + ((size_t)tile * 4 + wave) * (TBT * RB * 4 * 256) + lane * 4;   // this lane's X32 slots of the tile
+    char* xh = reinterpret_cast<char*>(a.X) + ((size_t)tile * 4 + wave) * (TBT * RB * 2 * 1024) + lane * 16;   // ... X16 slots
     auto layer_norm = [&](auto residual_tag, auto xhalf_tag, const float* lnp, auto emit) {
         constexpr bool RES = decltype(residual_tag)::value;
         constexpr bool XH = decltype(xhalf_tag)::value;
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if constexpr (RES && XH) {          // X16 order: one contiguous KiB of fp16 per load instruction
                         u32x4 rv;
                         if constexpr (XPRE) rv = res[(t * RB + rb) * 2 + s2];          // (requested at the top of the kernel)
-                        else rv = *reinterpret_cast<const u32x4*>(xh + ((t * RB + rb) * 2 + s2) * 1024);
+                        else rv = *reinterpret_cast<const u32x4*>(xh + ((gblock(t) * RB + rb) * 2 + s2) * 1024);
                         const uint32_t w4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     } else if constexpr (RES) {         // X32 order: one contiguous KiB per load instruction
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const float4 rv = *reinterpret_cast<const float4*>(xt + ((t * RB + rb) * 4 + 2 * s2 + e) * 256);
+                            const float4 rv = *reinterpret_cast<const float4*>(xt + ((gblock(t) * RB + rb) * 4 + 2 * s2 + e) * 256);
                             r8[4 * e + 0] = rv.x; r8[4 * e + 1] = rv.y; r8[4 * e + 2] = rv.z; r8[4 * e + 3] = rv.w;
                         }
                     }
@@ -295,7 +313,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         return bias;
     };
-    if constexpr (HIDT == 256) {
+    if constexpr (SUB) {
+        // Two token blocks per workgroup leave the registers for a software pipeline over the chunks: the accumulators
+        // of phase A exist twice, h in LDS twice, W1 in two register sets.  Iteration c:
+        //   first half   phase A of chunk c + 1 (32 MFMAs, panel fragments) with chunk c's h -- ReLU, pack, ds_write --
+        //                between the MFMAs; W2 of chunk c and W1 of chunk c + 2 requested
+        //   barrier      every wave's h of chunk c is in LDS (one barrier per chunk: buffer c & 1 is next written in
+        //                iteration c + 2, behind iteration c + 1's barrier, which no wave passes before all finished c)
+        //   second half  phase B of chunk c (32 MFMAs, h fragments); b1 of chunk c + 2 requested
+        // Chunk parity is a template argument (register sets and buffers alternate): the loop runs two chunks per trip.
+        u32x4 w1g[16];
+        f32x16 hacc[2][TB];
+        u32x4 braw[4];
+        auto h_write = [&](auto par_tag, auto t_tag, auto s_tag) {
+            constexpr int par = decltype(par_tag)::value, t = decltype(t_tag)::value, s2 = decltype(s_tag)::value;
+            const f32x16& hv = hacc[par][t];
+            const u32x4 frag = u32x4{P::relu2(P::pack2(hv[8 * s2 + 0], hv[8 * s2 + 1])), P::relu2(P::pack2(hv[8 * s2 + 2], hv[8 * s2 + 3])),
+                                     P::relu2(P::pack2(hv[8 * s2 + 4], hv[8 * s2 + 5])), P::relu2(P::pack2(hv[8 * s2 + 6], hv[8 * s2 + 7]))};
+            const uint32_t addr = hb0 + (uint32_t)(par * (TB * 8 * 1024) + (t * 8 + 2 * wave + s2) * 1024);
+            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
+        };
+        auto w1_of = [&](int c) { return a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024; };
+        const int nrun = (a.debug_mode & 2) ? 0 : NCH;
+        if (nrun > 0) {
+            // chunk 0's phase A (its W1 fragments were requested above into set 0); chunk 1's W1 into set 1
+            bias_read(braw, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const f32x16 bias0 = bias_of(braw);
+            vm_wait_all(w1f);
+            const char* w1n = w1_of(nrun > 1 ? 1 : 0);
+            stream<OffPanel<KS, 0, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                if constexpr (ks == 0) hacc[0][tb] = P::mma32(w1f[0], bf, bias0);
+                else hacc[0][tb] = P::mma32(w1f[ks], bf, hacc[0][tb]);
+                if constexpr (i % 2 == 0) gload_frag<i / 2>(w1g[i / 2], voff, w1n);
+                if constexpr (i == 20) bias_read(braw, nrun > 1 ? 1 : 0);
+            });
+        }
+        auto iter = [&](auto par_tag, auto next_tag, int c) {
+            constexpr int PAR = decltype(par_tag)::value;
+            constexpr bool NEXT = decltype(next_tag)::value;          // chunk c + 1 exists
+            u32x4 (&wa)[16] = *(PAR ? &w1f : &w1g);                   // W1 of chunk c + 1 (set (c + 1) & 1)
+            u32x4 (&wn)[16] = *(PAR ? &w1g : &w1f);                   // free: W1 of chunk c + 2 goes here
+            const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;
+            // W1 of chunk c + 2; behind the last chunks the first half-step of the Q/K/V tail, which expects it in set 0
+            // (parity 0 is the second to last chunk: NCH is even); anything else harmless
+            const char* nx = c + 2 < NCH ? w1_of(c + 2) : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1_of(c));
+            const int cb = c + 2 < NCH ? c + 2 : c;
+            f32x16 bias;
+            if constexpr (NEXT) bias = bias_of(braw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(wa[k]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NEXT) {
+                stream<OffPanel<KS, 0, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / TB, tb = i % TB;
+                    if constexpr (ks == 0) hacc[PAR ^ 1][tb] = P::mma32(wa[0], bf, bias);
+                    else hacc[PAR ^ 1][tb] = P::mma32(wa[ks], bf, hacc[PAR ^ 1][tb]);
+                    // (all 32 requests in the first half of the stream: they are waited for right behind the barrier)
+                    if constexpr (i < 16) { gload_frag<i>(w2f[i], voff, w2c); gload_frag<i>(wn[i], voff, nx); }
+                    if constexpr (i % 4 == 1 && i / 4 < 2 * TB)
+                        h_write(std::integral_constant<int, PAR>{}, std::integral_constant<int, (i / 4) / 2>{}, std::integral_constant<int, (i / 4) % 2>{});
+                });
+            } else {
+                [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(w2f[K], voff, w2c), ...); }(std::make_integer_sequence<int, 16>{});
+                [&]<int... U>(std::integer_sequence<int, U...>) {
+                    (h_write(std::integral_constant<int, PAR>{}, std::integral_constant<int, U / 2>{}, std::integral_constant<int, U % 2>{}), ...);
+                }(std::make_integer_sequence<int, 2 * TB>{});
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w2f[k]), "+v"(wn[k]));
+            __builtin_amdgcn_sched_barrier(0);
+            stream<OffH2<TB, PAR>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i / TB, tb = i % TB;
+                yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
+                yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                if constexpr (i == 2) bias_read(braw, cb);
+            });
+        };
+        for (int c = 0; c + 2 < nrun; c += 2) {
+            iter(std::integral_constant<int, 0>{}, std::true_type{}, c);
+            iter(std::integral_constant<int, 1>{}, std::true_type{}, c + 1);
+        }
+        if (nrun > 0) {
+            iter(std::integral_constant<int, 0>{}, std::true_type{}, nrun - 2);
+            iter(std::integral_constant<int, 1>{}, std::false_type{}, nrun - 1);
+        }
+    } else if constexpr (HIDT == 256) {
         // ONE fragment stream per chunk, 120 steps / 160 MFMAs, nothing of the hand-over exposed:
         //   steps   0.. 47  phase A, token blocks 0..2 (panel fragment (tb, ks), ks outer); this chunk's W2 fragments requested
         //   steps  48.. 79  phase A, token blocks 3, 4; the h of blocks 0..2 packed and written between the MFMAs
@@ -455,19 +566,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- LayerNorm-2 -> X (fp32 residual stream, X32 order: one KiB per store) and its row-major 16-bit copy
     layer_norm(std::false_type{}, std::false_type{}, lnp2, [&](int t, int rb, const f32x16& y) {
-        if (a.write_x && a.x_half) {                        // (the last layer's residual stream has no reader)
+        if (SUB && t >= nblk) {
+            // a token block past the tile's end: nothing of it is stored (the panel copy feeds the tail's MFMAs only)
+        } else if (a.write_x && a.x_half) {                 // (the last layer's residual stream has no reader)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
-                *reinterpret_cast<u32x4*>(xh + ((t * RB + rb) * 2 + s2) * 1024) = u32x4{pack_f16x2(y[8 * s2 + 0], y[8 * s2 + 1]), pack_f16x2(y[8 * s2 + 2], y[8 * s2 + 3]),
+                *reinterpret_cast<u32x4*>(xh + ((gblock(t) * RB + rb) * 2 + s2) * 1024) = u32x4{pack_f16x2(y[8 * s2 + 0], y[8 * s2 + 1]), pack_f16x2(y[8 * s2 + 2], y[8 * s2 + 3]),
                                                                                   pack_f16x2(y[8 * s2 + 4], y[8 * s2 + 5]), pack_f16x2(y[8 * s2 + 6], y[8 * s2 + 7])};
         } else if (a.write_x) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(xt + ((t * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+                *reinterpret_cast<float4*>(xt + ((gblock(t) * RB + rb) * 4 + q) * 256) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
         }
         if constexpr (QKV) panel_write(t, rb, y);          // x2: the B operand of the Q/K/V tail
         const int m = m0 + 32 * t + tok;
-        if (a.Xb && m < a.M) {
+        if (a.Xb && m < a.M && !(SUB && t >= nblk)) {
             char* brow = a.Xb + ((size_t)m * HIDT + fbase + 32 * rb + 16 * hh) * 2;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -478,27 +591,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(5);
 
     if constexpr (QKV) {
-        qkv_tail<P, HIDT>(a, smem, m0, w1f, w2f);
+        qkv_tail<P, HIDT, TBS>(a, smem, m0, w1f, w2f, nblk);
         pstamp(6);
     }
 }
 
 template <class P, int HIDT>
 hipError_t launch_layer32_h(const Layer32Args& a, hipStream_t s) {
-    using G = Geo<HIDT>;
-    if (a.F % HC || a.F < HC || a.M <= 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)G::L_B1 + (size_t)a.F * 4;
-    if (lds > 163840 || a.F > 8192) return hipErrorInvalidValue;
-    const dim3 grid((a.M + G::TOKS - 1) / G::TOKS);
-    auto launch = [&](auto kern) {
+    if (a.F % HC || a.F < HC || a.M <= 0 || a.F > 8192) return hipErrorInvalidValue;
+    auto launch = [&](auto kern, auto geo, int subs) {
+        using G = decltype(geo);
+        const size_t lds = (size_t)G::L_B1 + (size_t)a.F * 4;
+        if (lds > 163840) return hipErrorInvalidValue;
+        const int tiles = (a.M + 32 * tile_blocks(HIDT) - 1) / (32 * tile_blocks(HIDT));
         static ppg::LdsLimit limit;
         const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL(kern, dim3(tiles * subs), dim3(256), lds, s, a);
         return hipGetLastError();
     };
-    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true>);
-    return launch(layer32_kernel<P, HIDT, false>);
+    if constexpr (HIDT == 256) {
+        if (a.sub_tiles) {                 // two token blocks per workgroup, 3 workgroups per 160-token tile
+            if ((a.F / HC) % 2) return hipErrorInvalidValue;
+            if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true, 2>, Geo<HIDT, 2>{}, 3);
+            return launch(layer32_kernel<P, HIDT, false, 2>, Geo<HIDT, 2>{}, 3);
+        }
+    }
+    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true>, Geo<HIDT>{}, 1);
+    return launch(layer32_kernel<P, HIDT, false>, Geo<HIDT>{}, 1);
 }
 
 template <class P>

@@ -30,6 +30,67 @@ def shard_lpt(costs, world_size):
     return shards
 
 
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_cpus(local_rank, local_world, device=None):
+    """Pin this rank's process (its launch thread, and the reader / writer threads it spawns later) to its
+    own slice of host cores: the cores of the NUMA node its GPU hangs off when sysfs tells, split among the
+    ranks that share the node -- otherwise an equal slice of the cores the process may use.  Eight ranks
+    each running a ~13-launch / 0.7 ms Python loop plus I/O threads on one box otherwise migrate over all
+    cores and across sockets.  Returns the sorted core list (empty: nothing was changed).
+    PPGS_AMD_BIND_CPUS=0 disables."""
+    if os.environ.get('PPGS_AMD_BIND_CPUS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return []
+    allowed = sorted(os.sched_getaffinity(0))
+    local_world = max(int(local_world), 1)
+    if len(allowed) < 2 * local_world:
+        return []
+    def node_of(index):
+        try:
+            props = torch.cuda.get_device_properties(index)
+            bdf = f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0'
+            with open(f'/sys/bus/pci/devices/{bdf}/numa_node') as handle:
+                return int(handle.read())
+        except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+            return -1
+    cpus = None
+    if torch.cuda.is_available():
+        count = torch.cuda.device_count()
+
+        def gpu_of(rank):
+            return (rank if device is None else device) % count
+        sharers = {}
+        for rank in range(local_world):
+            sharers.setdefault(node_of(gpu_of(rank)), []).append(rank)
+        mine = node_of(gpu_of(local_rank))
+        if mine >= 0:
+            try:
+                with open(f'/sys/devices/system/node/node{mine}/cpulist') as handle:
+                    node_cpus = sorted(_cpulist(handle.read()) & set(allowed))
+                ranks = sharers[mine]
+                if len(node_cpus) >= 2 * len(ranks):
+                    per = len(node_cpus) // len(ranks)
+                    slot = ranks.index(local_rank)
+                    cpus = node_cpus[slot * per:(slot + 1) * per]
+            except (OSError, KeyError, ValueError):
+                cpus = None
+    if not cpus:
+        per = len(allowed) // local_world
+        cpus = allowed[local_rank * per:(local_rank + 1) * per]
+    if not cpus:
+        return []
+    os.sched_setaffinity(0, cpus)
+    return cpus
+
+
 def init(backend=None):
     """Initialise the default process group from the torchrun environment
     and bind this rank to its GPU.  Returns (rank, world_size)."""
@@ -38,6 +99,8 @@ def init(backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world_size > 1:
+        bind_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world_size)))
     if world_size > 1 and not dist.is_initialized():
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -66,6 +129,8 @@ def gather_ragged(local, frame_counts_local, dst=0):
     dist.all_gather_object(counts, [int(c) for c in frame_counts_local])
     totals = [sum(c) for c in counts]
     local = local.contiguous()
+    if dist.get_backend() != 'nccl' and local.is_cuda:
+        local = local.cpu()                 # (gloo moves host memory: the aliased-GPU dry run of bench.py)
     ops, buffers = [], {}
     if rank == dst:
         for src in range(world_size):

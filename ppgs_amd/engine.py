@@ -388,7 +388,9 @@ class Engine:
         where launch latency, not kernel time, sets the step rate.
 
         Returns ``run(features) -> posteriors``; the returned tensor is a
-        static buffer overwritten by the next call.
+        static buffer overwritten by the next call.  ``run.static_input`` is
+        the buffer the graph reads: a producer that writes it in place calls
+        ``run()`` without an argument and saves the copy.
         """
         lengths = [frames] * batch if lengths is None else lengths
         static_in = torch.zeros(
@@ -410,12 +412,16 @@ class Engine:
             # (under capture ppg_encode pins the cached plan: the graph holds its device pointers)
             static_out = self.encode(static_in, lengths, softmax, legacy_mode, workspace=scratch)
 
-        def run(features):
-            static_in.copy_(features, non_blocking=True)
+        def run(features=None):
+            # features=None: the caller's producer (e.g. the mel frontend) wrote run.static_input in place
+            if features is not None:
+                static_in.copy_(features, non_blocking=True)
             graph.replay()
             return static_out
         run.graph = graph
         run.scratch = scratch
+        run.static_input = static_in
+        run.static_output = static_out
         return run
 
     # -- per-kernel HIP-event timing (bench.py roofline leg) ----------------

@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: world_size 2 over gloo.  The per-batch compute is
+"""Multi-rank path on CPU: world_size 2 (and 4, with an empty shard) over gloo.  The per-batch compute is
 the CPU oracle here (test infrastructure); sharding, packing, the two gather
 collectives and the reassembly are the product code under test."""
 import os
@@ -118,3 +118,53 @@ def test_two_rank_file_sharding(tmp_path):
     shards = distributed.shard_lpt([data.flops(n // 160) for n in lengths], WORLD)
     assert [owners[i] for i in shards[0]] == [0] * len(shards[0])
     assert [owners[i] for i in shards[1]] == [1] * len(shards[1])
+
+
+def worker4(rank, port, world, lengths, result_path):
+    os.environ.update(
+        MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+        WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import ppg_oracle
+    from ppgs_amd import data, distributed, weights
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cpus = distributed.bind_cpus(rank, world)
+    assert cpus == [] or sorted(os.sched_getaffinity(0)) == cpus
+    state = weights.seeded_state_dict(seed=1234, num_layers=1)
+    generator = torch.Generator().manual_seed(6)
+    audios = [0.1 * torch.randn(1, n * 160, generator=generator) for n in lengths]
+    shards = distributed.shard_lpt([data.flops(n) for n in lengths], world)
+
+    def audio_of(index):
+        assert index in shards[rank], (rank, index)
+        return audios[index]
+
+    def compute(padded, sample_lengths):
+        return ppg_oracle.from_audio(state, padded)
+
+    out = distributed.from_audios_sharded(audio_of, compute=compute, max_frames=400, frames=list(lengths))
+    if rank == 0:
+        torch.save({'out': out, 'empty': [r for r, shard in enumerate(shards) if not shard]}, result_path)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_with_an_empty_shard(tmp_path):
+    """World size 4 over three utterances: one rank gets nothing (it still takes part in the count exchange and
+    sends no payload), the other three one utterance each; rank 0 reassembles all of them in input order."""
+    world, lengths = 4, [70, 45, 110]
+    result = tmp_path / 'result4.pt'
+    mp.spawn(worker4, args=(free_port(), world, lengths, str(result)), nprocs=world, join=True)
+    got = torch.load(result)
+    assert len(got['empty']) == 1
+    from oracle import ppg_oracle
+    from ppgs_amd import weights
+    state = weights.seeded_state_dict(seed=1234, num_layers=1)
+    generator = torch.Generator().manual_seed(6)
+    audios = [0.1 * torch.randn(1, n * 160, generator=generator) for n in lengths]
+    for index, n in enumerate(lengths):
+        ref = ppg_oracle.from_audio(state, audios[index][None])[0]
+        assert got['out'][index].shape == (40, n)
+        assert np.abs(got['out'][index].numpy() - ref[:, :n].numpy()).max() < 1e-6

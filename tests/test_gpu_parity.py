@@ -218,7 +218,7 @@ def test_stagewise_small_models(layers):
     lengths = torch.tensor([75, 40])
     ref = O.from_features(state, feats, lengths, softmax=False).numpy()
     out = run(engine, feats, lengths, softmax=False)
-    assert np.abs(out - ref).max() < 2e-4
+    assert np.abs(out - ref).max() < FP32_TOL
 
 
 def test_single_window_fp32(golden):
@@ -284,8 +284,8 @@ def test_c1_entry_point(golden, tmp_path):
             t(g['audio']), 16000, checkpoint=str(path), gpu=0)
         assert ppg.shape == (1, 40, 100) and ppg.dtype == torch.float32
         assert ppg.is_cuda
-        # end to end includes rare fp16 feature flips of the frontend
-        assert np.abs(ppg.cpu().numpy() - g['ppg']).max() < 2e-4
+        # end to end includes rare fp16 feature flips of the frontend: still inside the north star's 1e-4
+        assert np.abs(ppg.cpu().numpy() - g['ppg']).max() < FP32_TOL
         feats = t(g['mel16']).cuda()
         ppg = ppgs_amd.from_features(
             feats, torch.tensor([100]), checkpoint=str(path), gpu=0)
@@ -639,7 +639,7 @@ def test_c2_full_size_statistics(golden):
     mel = ppgs_amd.preprocess.mel.from_audios(audio)
     assert mel.shape == (32, 80, 1000)
     assert np.abs(mel.float().sum(dim=(1, 2)).cpu().numpy() - g['mel_sum']).max() < 2.0
-    for precision, tol in (('fp32', 2e-4), ('bf16', BF16_TOL), ('fp16', FP16_TOL)):
+    for precision, tol in (('fp32', FP32_TOL), ('bf16', BF16_TOL), ('fp16', FP16_TOL)):
         engine, _ = eng(precision=precision)
         ppg = engine.encode(mel, [1000] * 32)
         torch.cuda.synchronize()
@@ -727,7 +727,7 @@ def test_c4_bucketed_ragged_utterances_vs_oracle():
         ref = O.from_features(state, mel.float(), [frames[i] for i in batch]).numpy()
         for row, index in enumerate(batch):
             err = np.abs(out[index].numpy() - ref[row, :, :frames[index]]).max()
-            assert err < 2e-4, (index, err)
+            assert err < FP32_TOL, (index, err)
 
 
 def test_c5_causal_streaming_chunks_and_graph_replay():
@@ -840,11 +840,12 @@ def test_multi_stream_groups_agree(monkeypatch):
 
 
 def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
-    """configs[2]: w2v2fb representation.  The wav2vec2 body is the
-    reference's third-party HF model (seeded random init offline) run on the
-    GPU by PyTorch-ROCm; its latents match the same model on the CPU, and the
-    768-channel / hidden-512 PPG network on top runs in the HIP engine and
-    matches the oracle on the same latents."""
+    """configs[2]: w2v2fb representation.  The wav2vec2 model is the
+    reference's third-party HF architecture (seeded random init offline); its
+    feature encoder AND its transformer body run on the HIP engine (ppg_w2v2_*,
+    ppg_w2v2_body_*): the latents match the same HF model run by PyTorch on the
+    CPU, and the 768-channel / hidden-512 PPG network on top runs in the HIP
+    engine and matches the oracle on the same latents."""
     monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
     import transformers
     from ppgs_amd.preprocess import w2v2fb
@@ -1104,3 +1105,97 @@ def test_w2v2_feature_encoder_c3_size(golden):
     assert (out[[0, 7, 15]] - ref).abs().max() < 2e-4
     fast = E.W2v2FeatureEncoder(model.feature_extractor.state_dict(), 0, 'fp16')(audio)
     assert (fast[[0, 7, 15]] - ref).abs().max() < 3e-2
+
+
+def test_c3_full_size_body_and_ppg_network(monkeypatch):
+    """configs[2] at its full size, 16 x 160000 samples -> (16, 768, 1000) -> (16, 40, 1000), all on the
+    HIP engine in fp32 mode: the w2v2fb latents (feature encoder + 12-layer body + upsampling) against the
+    same seeded HF model run by PyTorch-ROCm on spot items (fp16 latents within 2e-4 + one fp16 rounding,
+    different in < 5 % of the values; the body alone is held to 1e-4 by the G12 fixture), and the hidden-512 PPG network on those
+    latents against the CPU oracle on spot items, 1e-4."""
+    monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
+    from ppgs_amd.preprocess import w2v2fb
+    w2v2fb._models.clear()
+    old = ppgs_amd.core.PRECISION
+    ppgs_amd.core.PRECISION = 'fp32'
+    try:
+        gen = torch.Generator().manual_seed(12)
+        audio = 0.1 * torch.randn(16, 1, 160000, generator=gen)
+        lengths = torch.full((16,), 160000)
+        lengths[5], lengths[11] = 123456, 40000
+        for row in (5, 11):
+            audio[row, :, int(lengths[row]):] = 0
+        feats = w2v2fb.from_audios(audio, lengths, gpu=0)
+        assert feats.shape == (16, 768, 1000) and feats.dtype == torch.float16
+        model = w2v2fb.model_for(torch.device('cuda', 0))
+        spots = [0, 5, 11]
+        with torch.no_grad():
+            padded = torch.nn.functional.pad(audio[spots].cuda(), (40, 40)).squeeze(1)
+            positions = torch.arange(160080, device='cuda') - 80
+            mask = (positions[None] < lengths[spots].cuda()[:, None]).long()
+            ref = model(padded, mask).last_hidden_state.transpose(1, 2)
+            ref = torch.nn.functional.interpolate(ref, size=1000, mode='nearest').half()
+        for row, item in enumerate(spots):
+            valid = int(lengths[item]) // 160
+            # fp16 latents of magnitude ~4: equal up to one fp16 rounding flip (HIP engine fp32 vs PyTorch-ROCm fp32)
+            got, want = feats[item, :, :valid].cpu().numpy(), ref[row, :, :valid].cpu().numpy()
+            diff = np.abs(got.astype(np.float32) - want.astype(np.float32))
+            ulp = np.spacing(np.maximum(np.abs(got), np.abs(want))).astype(np.float32)
+            # (the fp32 latents agree to ~1e-4 -- the bar G11 / G12 hold the two stages to; then one fp16 rounding)
+            assert (diff <= 2e-4 + ulp).all() and (diff > 0).mean() < 0.05, item
+        state = W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512)
+        engine = E.Engine(state, 0, 'fp32')
+        frames = (lengths // 160).tolist()
+        ppg = engine.encode(feats, frames)
+        assert ppg.shape == (16, 40, 1000) and bool(torch.isfinite(ppg).all())
+        oracle = O.from_features(state, feats[spots].cpu(), [frames[i] for i in spots]).numpy()
+        for row, item in enumerate(spots):
+            assert np.abs(ppg[item, :, :frames[item]].cpu().numpy() - oracle[row, :, :frames[item]]).max() < FP32_TOL, item
+        # the 16-bit modes on the same latents
+        for precision in ('fp16', 'bf16'):
+            fast = E.Engine(state, 0, precision).encode(feats, frames)
+            for row, item in enumerate(spots):
+                assert np.abs(fast[item, :, :frames[item]].cpu().numpy() - oracle[row, :, :frames[item]]).max() < TOL[precision], (precision, item)
+    finally:
+        ppgs_amd.core.PRECISION = old
+        w2v2fb._models.clear()
+
+
+def test_c4_thousand_utterances_slice():
+    """configs[3], a 1000-utterance slice of the benchmark corpus (frame counts randint(50, 3001), seed 1234,
+    the first 1000 of the 10 000): packed under max_frames = 32000 with the row budget the benchmark uses,
+    run through the sharded entry point; every output has its utterance's frame count, rows are distributions,
+    and utterances spot-checked against the oracle on their own padded batch (first / middle / last batch:
+    the longest, a middle and the shortest bucket) are within 1e-4 in fp32 mode."""
+    from ppgs_amd import data, distributed
+    gen = torch.Generator().manual_seed(1234)
+    frames = torch.randint(50, 3001, (10000,), generator=gen).tolist()[:1000]
+    agen = torch.Generator().manual_seed(99)
+    audios = [0.1 * torch.randn(1, f * 160, generator=agen) for f in frames]
+    state = W.seeded_state_dict(seed=1234)
+    engine, _ = eng()
+
+    def compute(padded, lengths):
+        mel = ppgs_amd.preprocess.mel.from_audios(padded.cuda())
+        return engine.encode(mel, lengths // 160).cpu()
+
+    out = distributed.from_audios_sharded(audios, compute=compute, max_frames=32000)
+    assert [o.shape for o in out] == [(40, f) for f in frames]
+    total = torch.cat([o.sum(0) for o in out])
+    assert (total - 1).abs().max() < 1e-5
+    # the batches exactly as from_audios_sharded formed them (one rank: the LPT order, frame AND row budget)
+    mine = distributed.shard_lpt([data.flops(f) for f in frames], 1)[0]
+    packed = data.pack_batches([frames[i] for i in mine], 32000, max_rows=data.row_budget(32000, gpu=None))
+    batches = [[mine[j] for j in batch] for batch in packed]
+    assert all(len(b) * max(frames[i] for i in b) <= 32000 for b in batches)
+    assert sorted(i for b in batches for i in b) == list(range(1000))
+    for batch in (batches[0], batches[len(batches) // 2], batches[-1]):
+        keep = batch[:2] + batch[-1:]
+        padded, _ = data.collate([audios[i] for i in batch])
+        mel = O.mel_from_audios(padded)
+        rows = [batch.index(i) for i in keep]
+        # (the oracle on the spot rows only, at the batch's padded length: batch composition sets the halo frames)
+        ref = O.from_features(state, mel[rows].float(), [frames[i] for i in keep]).numpy()
+        for row, index in enumerate(keep):
+            err = np.abs(out[index].numpy() - ref[row, :, :frames[index]]).max()
+            assert err < FP32_TOL, (index, err)
