@@ -67,6 +67,10 @@ template <int K>
 __device__ __forceinline__ void gload_frag(u32x4& dst, uint32_t voff, const char* base) {
     gload128<(K % 4) * 1024>(dst, voff, base + (K / 4) * 4096);
 }
+template <int K>
+__device__ __forceinline__ void gload_frag_acc(u32x4& dst, uint32_t voff, const char* base) {
+    gload128_acc<(K % 4) * 1024>(dst, voff, base + (K / 4) * 4096);
+}
 // every load issued so far has landed; the registers are tied so no use moves above
 template <int COUNT>
 __device__ __forceinline__ void vm_wait_all(u32x4 (&r)[COUNT]) {

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         //                iteration c + 2, behind iteration c + 1's barrier, which no wave passes before all finished c)
         //   second half  phase B of chunk c (32 MFMAs, h fragments); b1 of chunk c + 2 requested
         // Chunk parity is a template argument (register sets and buffers alternate): the loop runs two chunks per trip.
-        u32x4 w1g[16];
+        u32x4 w1g[16], w2g[16];
         f32x16 hacc[2][TB];
         u32x4 braw[4];
         auto h_write = [&](auto par_tag, auto t_tag, auto s_tag) {
@@ -334,20 +334,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
         };
         auto w1_of = [&](int c) { return a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024; };
+        auto w2_of = [&](int c) { return a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024; };
+        // Weight traffic: 128 KiB per chunk and CU against 64 MFMAs per wave -- at the vector memory path's ~64 B / clk the
+        // fragments take as long to arrive as the MFMAs to issue, and a burst of requests stalls the wave that issues it
+        // (32 requests in 16 steps: 4.2 - 4.4 k cycles per chunk; spread evenly: 3.1 k).  So requests are spread over the
+        // whole iteration and waited for with COUNTED vmcnt (16 requests per half: vmcnt(16) = "all but the newest half"):
+        //   first half of iteration c    requests W1 of chunk c + 2 (needed at the top of iteration c + 1)
+        //   second half                  requests W2 of chunk c + 1 (needed behind iteration c + 1's barrier)
+        // The two W2 sets live in the ACCUMULATION registers (loads write
+        // either file, an MFMA reads its A operand from either): four sets in the 256 architectural registers made the
+        // compiler park one in the other file, with copies right behind the asm loads -- of data not yet there (NaNs).
         const int nrun = (a.debug_mode & 2) ? 0 : NCH;
         if (nrun > 0) {
-            // chunk 0's phase A (its W1 fragments were requested above into set 0); chunk 1's W1 into set 1
+            // chunk 0's phase A (its W1 fragments were requested above into set 0); W1 of chunk 1, then W2 of chunk 0
             bias_read(braw, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const f32x16 bias0 = bias_of(braw);
             vm_wait_all(w1f);
             const char* w1n = w1_of(nrun > 1 ? 1 : 0);
+            const char* w20 = w2_of(0);
             stream<OffPanel<KS, 0, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ks = i / TB, tb = i % TB;
                 if constexpr (ks == 0) hacc[0][tb] = P::mma32(w1f[0], bf, bias0);
                 else hacc[0][tb] = P::mma32(w1f[ks], bf, hacc[0][tb]);
-                if constexpr (i % 2 == 0) gload_frag<i / 2>(w1g[i / 2], voff, w1n);
+                if constexpr (i < 16) gload_frag<i>(w1g[i], voff, w1n);
+                else gload_frag_acc<i - 16>(w2f[i - 16], voff, w20);
                 if constexpr (i == 20) bias_read(braw, nrun > 1 ? 1 : 0);
             });
         }
@@ -356,14 +368,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr bool NEXT = decltype(next_tag)::value;          // chunk c + 1 exists
             u32x4 (&wa)[16] = *(PAR ? &w1f : &w1g);                   // W1 of chunk c + 1 (set (c + 1) & 1)
             u32x4 (&wn)[16] = *(PAR ? &w1g : &w1f);                   // free: W1 of chunk c + 2 goes here
-            const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;
+            u32x4 (&w2c)[16] = *(PAR ? &w2g : &w2f);                  // W2 of chunk c
+            u32x4 (&w2n)[16] = *(PAR ? &w2f : &w2g);                  // free: W2 of chunk c + 1 goes here
             // W1 of chunk c + 2; behind the last chunks the first half-step of the Q/K/V tail, which expects it in set 0
             // (parity 0 is the second to last chunk: NCH is even); anything else harmless
             const char* nx = c + 2 < NCH ? w1_of(c + 2) : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1_of(c));
+            const char* nx2 = w2_of(c + 1 < NCH ? c + 1 : c);
             const int cb = c + 2 < NCH ? c + 2 : c;
             f32x16 bias;
             if constexpr (NEXT) bias = bias_of(braw);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // in flight: [W1 of chunk c + 1 (or its stand-in)] [W2 of chunk c], 16 requests each, in this order
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(wa[k]));
             __builtin_amdgcn_sched_barrier(0);
@@ -373,28 +388,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     constexpr int ks = i / TB, tb = i % TB;
                     if constexpr (ks == 0) hacc[PAR ^ 1][tb] = P::mma32(wa[0], bf, bias);
                     else hacc[PAR ^ 1][tb] = P::mma32(wa[ks], bf, hacc[PAR ^ 1][tb]);
-                    // (all 32 requests in the first half of the stream: they are waited for right behind the barrier)
-                    if constexpr (i < 16) { gload_frag<i>(w2f[i], voff, w2c); gload_frag<i>(wn[i], voff, nx); }
+                    if constexpr (i % 2 == 0) gload_frag<i / 2>(wn[i / 2], voff, nx);
                     if constexpr (i % 4 == 1 && i / 4 < 2 * TB)
                         h_write(std::integral_constant<int, PAR>{}, std::integral_constant<int, (i / 4) / 2>{}, std::integral_constant<int, (i / 4) % 2>{});
                 });
             } else {
-                [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(w2f[K], voff, w2c), ...); }(std::make_integer_sequence<int, 16>{});
                 [&]<int... U>(std::integer_sequence<int, U...>) {
                     (h_write(std::integral_constant<int, PAR>{}, std::integral_constant<int, U / 2>{}, std::integral_constant<int, U % 2>{}), ...);
                 }(std::make_integer_sequence<int, 2 * TB>{});
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // in flight: [W2 of chunk c] [W1 of chunk c + 2: 16 requests, if this iteration made them]
+            if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w2f[k]), "+v"(wn[k]));
+            for (int k = 0; k < 16; ++k) asm volatile("" : "+a"(w2c[k]));
             __builtin_amdgcn_sched_barrier(0);
             stream<OffH2<TB, PAR>, 8 * TB, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int ks = i / TB, tb = i % TB;
-                yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
-                yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                yacc[0][tb] = P::mma32(w2c[ks], bf, yacc[0][tb]);
+                yacc[1][tb] = P::mma32(w2c[8 + ks], bf, yacc[1][tb]);
+                if constexpr (NEXT) gload_frag_acc<i>(w2n[i], voff, nx2);
                 if constexpr (i == 2) bias_read(braw, cb);
             });
         };
