@@ -306,6 +306,19 @@ int ppg_stream_rows(const PpgStream* stream, int* rows, int* received_frames, in
 const float* ppg_stream_posteriors(const PpgStream* stream);
 int ppg_stream_push(PpgStream* stream, const void* chunk_device, int n_frames, int flush, int softmax,
                     int* first_final, int* num_final, void* hip_stream);
+/*
+ * The same for `batch` utterances advanced together (configs[4] is "streaming chunks, batch = 64",
+ * ppgs/config/causal_transformer.py:18): one stream object, item b an utterance of its own with its own frontier.
+ * ppg_stream_push_batch takes chunk (batch, input_channels, n_max) on the device and, per item, how many of its
+ * n_max columns are new frames (counts_host[b] in [0, n_max], ragged; 0 and no flush = the item sits this step out)
+ * and whether the item ends (flush_host, may be null); ONE launch sequence advances all items.  Posteriors:
+ * (batch, output_channels, rows) fp32 at ppg_stream_posteriors(); first_final / num_final are per item.
+ * An item equals the causal forward of its own utterance (as the one-utterance stream does).
+ */
+int ppg_stream_create_batch(PpgEngine* engine, int batch, int max_frames, int feature_dtype, PpgStream** stream);
+int ppg_stream_batch(const PpgStream* stream);
+int ppg_stream_push_batch(PpgStream* stream, const void* chunk_device, int n_max, const int* counts_host,
+                          const int* flush_host, int softmax, int* first_final, int* num_final, void* hip_stream);
 
 /*
  * wav2vec 2.0 feature encoder of the 'w2v2fb' representation (reference

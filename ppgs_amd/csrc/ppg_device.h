@@ -285,6 +285,8 @@ struct LinearArgs {
     float* out32;             // fp32 [M][out_ld32], or null
     int out_ld32;
     int act_y_stride;         // bytes added to `act` per blockIdx.y (grouped convolution: group y reads its own channels)
+    const int* rowmap;        // see GatherArgs (16 tokens per wave only)
+    int map_blocks;
 };
 
 struct FfnArgs {
@@ -316,6 +318,8 @@ struct FfnArgs {
     unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
     float* partial;           // split-hidden mode: [splits][M][H] fp32 partial sums, else null
     int splits;
+    const int* rowmap;        // see GatherArgs (16 tokens per wave, no hidden splits)
+    int map_blocks;
 };
 
 // Memory laid out for the feature-split layer kernel (160-token workgroup tiles):
@@ -428,6 +432,10 @@ struct GatherArgs {
     int nwin;
     char* qk_slack;           // the rows behind the last token of the q|k buffer
     int qk_slack_bytes;       // multiple of 16
+    // Row map (batched streaming: a step touches a few 16-row blocks of every stream's window): slot k of the launch
+    // works on token rows rowmap[k] .. + 15 instead of 16 k ..; slots past map_blocks hold M (nothing to do)
+    const int* rowmap;
+    int map_blocks;
 };
 
 // Window of a token row (the planner numbers rows window by window, every window padded to 16 rows)

@@ -1353,69 +1353,122 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
 // row0, the window table's tok_off lowered by row0 so that window positions
 // (PE, masks, V^T columns) stay absolute.
 // ----------------------------------------------------------------------------
+// A stream object holds `batch` utterances (ppg_stream_create: one), each ONE window of up to `cap` frames, in one
+// token space: item b owns rows b R .. (b + 1) R - 1 of every buffer (R = cap rounded up to 32), its own window
+// record (position b R, valid = its frontier) and its own K | Q / V^T rows in the per-layer caches.  A step advances
+// all items by their own -- ragged, unaligned -- numbers of frames in ONE launch sequence: the launches of the
+// token-split kernels take a ROW MAP (the 16-row blocks the step touches, of any items, one per wave) instead of a
+// contiguous row range, the attention launch takes the items' query tiles.  Rows are recomputed from the last block
+// boundary at or below an item's previous frontier; a recomputed row gives the same bits (the hidden chunks are
+// walked in a fixed order under a row map).
+struct StreamItemMeta { int row0; int received_before; int count; int pad; };
+__global__ void stream_append_kernel(const StreamItemMeta* meta, const char* chunk, int nmax, int C, int R, int esz, char* feats) {
+    const int b = blockIdx.y;
+    const StreamItemMeta m = meta[b];
+    const int total = C * m.count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / m.count, t = i - c * m.count;
+        const char* src = chunk + (((size_t)b * C + c) * nmax + t) * esz;
+        char* dst = feats + (((size_t)b * C + c) * R + m.received_before + t) * esz;
+        if (esz == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+        else *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+    }
+}
+
 struct PpgStream {
     PpgEngine* e = nullptr;
-    int cap = 0, rows = 0, dtype = 0;
+    int batch = 1, cap = 0, rows = 0, dtype = 0;      // rows = R, per item
     Workspace ws{};
     char* buf = nullptr;          // workspace
-    char* feats = nullptr;        // (C, rows) in `dtype`
-    float* probs = nullptr;       // (output_channels, rows)
+    char* feats = nullptr;        // (batch, C, rows) in `dtype`
+    float* probs = nullptr;       // (batch, output_channels, rows)
     int* d_blk = nullptr;
-    PpgWindow* d_win = nullptr;   // [0] gather / linear launches, [1] out-conv
-    AttnItem* d_items = nullptr;
-    size_t qk_bytes = 0, vt_bytes = 0, cache_off = 0;
-    int received = 0, x_valid = 0, o_valid = 0;
-    bool finished = false;
-    // the per-step tables go up from pinned slots (a step's uploads are asynchronous: the source must outlive the call)
-    static constexpr int kSlots = 8, kMaxItems = 16;
-    struct Staging { PpgWindow win[3]; AttnItem items[kMaxItems]; };
-    Staging* staging = nullptr;
+    char* d_tables = nullptr;     // one step's tables (layout: Tables)
+    size_t qk_bytes = 0, vt_bytes = 0, cache_off = 0, part_off = 0;
+    int max_splits = 1;           // hidden splits of the FFN launches (a step's few rows cannot stream the weights through few CUs fast enough)
+    std::vector<int> received, x_valid, o_valid;
+    std::vector<char> finished;
+    std::vector<int> map_scratch;
+    // per-step tables, uploaded with ONE copy from a pinned slot (asynchronous: the source must outlive the call)
+    struct Tables {
+        size_t win = 0, meta = 0, items = 0, maps = 0, bytes = 0;   // byte offsets: win[3][batch], meta[batch], items[max_items], maps[3][max_blocks]
+        int max_items = 0, max_blocks = 0;
+    } tb;
+    static constexpr int kSlots = 8;
+    char* staging = nullptr;
     hipEvent_t uploaded[kSlots] = {};
     unsigned step = 0;
     ~PpgStream() {
         if (e) (void)hipSetDevice(e->device);
-        for (void* p : {(void*)buf, (void*)feats, (void*)probs, (void*)d_blk, (void*)d_win, (void*)d_items}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)buf, (void*)feats, (void*)probs, (void*)d_blk, (void*)d_tables}) if (p) (void)hipFree(p);
         if (staging) (void)hipHostFree(staging);
         for (hipEvent_t ev : uploaded) if (ev) (void)hipEventDestroy(ev);
     }
 };
 
-int ppg_stream_create(PpgEngine* e, int max_frames, int feature_dtype, PpgStream** out) {
+int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature_dtype, PpgStream** out) {
     if (!e || !out) return fail(PPG_EINVAL, "null argument");
     if (!e->cfg.is_causal) return fail(PPG_EINVAL, "streaming needs a causal engine (is_causal = 1)");
+    if (batch < 1 || batch > 4096) return fail(PPG_EINVAL, "batch %d outside [1, 4096]", batch);
     if (max_frames < 1 || max_frames > e->cfg.chunk_length)
         return fail(PPG_ELENGTH, "max_frames %d outside [1, %d] (one window)", max_frames, e->cfg.chunk_length);
     if (feature_dtype != PPG_DTYPE_F16 && feature_dtype != PPG_DTYPE_F32) return fail(PPG_EINVAL, "feature dtype %d", feature_dtype);
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_OK(hipSetDevice(e->device));
     std::unique_ptr<PpgStream> st(new PpgStream);
-    st->e = e; st->cap = max_frames; st->rows = round_up(max_frames, 32); st->dtype = feature_dtype;
+    st->e = e; st->batch = batch; st->cap = max_frames; st->rows = round_up(max_frames, 32); st->dtype = feature_dtype;
+    st->received.assign(batch, 0); st->x_valid.assign(batch, 0); st->o_valid.assign(batch, 0); st->finished.assign(batch, 0);
     const PpgConfig& c = e->cfg;
-    st->ws = layout(e, st->rows, st->rows);
-    // hidden splits are chosen per step from the rows of the step: room for the most there can be
-    const int chunks = c.ffn_channels / (32768 / (c.hidden_channels * e->sz));
-    const size_t part_bytes = (size_t)std::max(1, chunks / 2) * st->rows * c.hidden_channels * 4;
+    const int R = st->rows, MT = batch * R;
+    st->ws = layout(e, MT, MT);
     // K | Q rows and V^T per LAYER (the one-shot forward reuses one pair for all layers; here they are the cache)
     st->qk_bytes = align_up((size_t)st->ws.qk_rows * 2 * c.hidden_channels * e->sz, 256);
     st->vt_bytes = align_up((size_t)c.hidden_channels * st->ws.vt_ld * e->sz, 256);
-    st->cache_off = align_up(st->ws.total + part_bytes, 256);
+    // partial sums of the split-hidden FFN launches: [splits][batch * R][H] fp32, at most 256 MiB
+    {
+        const int chunks = c.ffn_channels / (32768 / (c.hidden_channels * e->sz));
+        const size_t per_split = (size_t)MT * c.hidden_channels * 4;
+        st->max_splits = 1;
+        while (st->max_splits * 2 <= std::max(1, chunks / 2) && (size_t)(st->max_splits * 2) * per_split <= ((size_t)256 << 20)) st->max_splits *= 2;
+        st->part_off = align_up(st->ws.total, 256);
+        st->cache_off = align_up(st->part_off + (st->max_splits > 1 ? st->max_splits * per_split : 0), 256);
+    }
     const size_t bytes = st->cache_off + (size_t)c.num_layers * (st->qk_bytes + st->vt_bytes);
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->buf), bytes));
     HIP_OK(hipMemset(st->buf, 0, bytes));
     const size_t esz = feature_dtype == PPG_DTYPE_F16 ? 2 : 4;
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->feats), (size_t)c.input_channels * st->rows * esz));
-    HIP_OK(hipMemset(st->feats, 0, (size_t)c.input_channels * st->rows * esz));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->probs), (size_t)c.output_channels * st->rows * 4));
-    HIP_OK(hipMemset(st->probs, 0, (size_t)c.output_channels * st->rows * 4));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_blk), (st->rows / 16 + 8) * sizeof(int)));
-    HIP_OK(hipMemset(st->d_blk, 0, (st->rows / 16 + 8) * sizeof(int)));          // every block belongs to window 0
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_win), 3 * sizeof(PpgWindow)));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_items), PpgStream::kMaxItems * sizeof(AttnItem)));
-    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&st->staging), PpgStream::kSlots * sizeof(PpgStream::Staging), hipHostMallocDefault));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->feats), (size_t)batch * c.input_channels * R * esz));
+    HIP_OK(hipMemset(st->feats, 0, (size_t)batch * c.input_channels * R * esz));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->probs), (size_t)batch * c.output_channels * R * 4));
+    HIP_OK(hipMemset(st->probs, 0, (size_t)batch * c.output_channels * R * 4));
+    // block -> window: block k belongs to item k / (R / 16)
+    {
+        std::vector<int> blk(MT / 16 + 8, -1);
+        for (int k = 0; k < MT / 16; ++k) blk[k] = k / (R / 16);
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_blk), blk.size() * sizeof(int)));
+        HIP_OK(hipMemcpy(st->d_blk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    PpgStream::Tables& tb = st->tb;
+    const int tile = e->head_dim == 128 ? ppg::attn_query_tile(e->head_dim) / 2 : ppg::attn_query_tile(e->head_dim);
+    tb.max_items = batch * (R / tile + 1);
+    tb.max_blocks = round_up(MT / 16, 4) + 4;
+    size_t off = 0;
+    tb.win = off; off = align_up(off + 3 * (size_t)batch * sizeof(PpgWindow), 64);
+    tb.meta = off; off = align_up(off + (size_t)batch * sizeof(StreamItemMeta), 64);
+    tb.items = off; off = align_up(off + (size_t)tb.max_items * sizeof(AttnItem), 64);
+    tb.maps = off; off = align_up(off + 3 * (size_t)tb.max_blocks * sizeof(int), 64);
+    tb.bytes = off;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_tables), tb.bytes));
+    HIP_OK(hipMemset(st->d_tables, 0, tb.bytes));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&st->staging), PpgStream::kSlots * tb.bytes, hipHostMallocDefault));
     for (hipEvent_t& ev : st->uploaded) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_OK(hipDeviceSynchronize());
     *out = st.release();
     return PPG_OK;
+}
+
+int ppg_stream_create(PpgEngine* e, int max_frames, int feature_dtype, PpgStream** out) {
+    return ppg_stream_create_batch(e, 1, max_frames, feature_dtype, out);
 }
 
 void ppg_stream_destroy(PpgStream* stream) { delete stream; }
@@ -1423,41 +1476,96 @@ void ppg_stream_destroy(PpgStream* stream) { delete stream; }
 int ppg_stream_rows(const PpgStream* st, int* rows, int* received, int* final_frames) {
     if (!st) return fail(PPG_EINVAL, "null argument");
     if (rows) *rows = st->rows;
-    if (received) *received = st->received;
-    if (final_frames) *final_frames = st->o_valid;
+    if (received) *received = st->received[0];
+    if (final_frames) *final_frames = st->o_valid[0];
     return PPG_OK;
 }
 
+int ppg_stream_batch(const PpgStream* st) { return st ? st->batch : 0; }
+
 const float* ppg_stream_posteriors(const PpgStream* st) { return st ? st->probs : nullptr; }
 
-int ppg_stream_push(PpgStream* st, const void* chunk, int n, int flush, int softmax,
-                    int* first_final, int* num_final, void* stream_) {
-    if (!st || (n > 0 && !chunk) || n < 0) return fail(PPG_EINVAL, "bad argument");
-    if (st->finished) return fail(PPG_EINVAL, "the stream was flushed");
-    if (st->received + n > st->cap) return fail(PPG_ELENGTH, "%d + %d frames > max_frames %d", st->received, n, st->cap);
+int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int* counts, const int* flush, int softmax,
+                          int* first_final, int* num_final, void* stream_) {
+    if (!st || !counts || nmax < 0) return fail(PPG_EINVAL, "bad argument");
     PpgEngine* e = st->e;
+    const int B = st->batch, R = st->rows;
+    bool any_frames = false;
+    for (int b = 0; b < B; ++b) {
+        const int n = counts[b];
+        if (n < 0 || n > nmax) return fail(PPG_EINVAL, "item %d: %d frames outside [0, %d]", b, n, nmax);
+        if (n > 0 || (flush && flush[b])) {
+            if (st->finished[b]) return fail(PPG_EINVAL, "item %d: the stream was flushed", b);
+            if (st->received[b] + n > st->cap) return fail(PPG_ELENGTH, "item %d: %d + %d frames > max_frames %d", b, st->received[b], n, st->cap);
+        }
+        any_frames = any_frames || n > 0;
+    }
+    if (any_frames && !chunk) return fail(PPG_EINVAL, "null chunk");
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const PpgConfig& c = e->cfg;
-    const int H = c.hidden_channels, F = c.ffn_channels, prec = c.precision, R = st->rows;
-    const size_t esz = st->dtype == PPG_DTYPE_F16 ? 2 : 4;
+    const int H = c.hidden_channels, F = c.ffn_channels, prec = c.precision, MT = B * R;
+    const int esz = st->dtype == PPG_DTYPE_F16 ? 2 : 4;
+    const PpgStream::Tables& tb = st->tb;
 
-    const int f_prev = st->received;
-    if (n > 0)
-        HIP_OK(hipMemcpy2DAsync(st->feats + (size_t)f_prev * esz, (size_t)R * esz, chunk, (size_t)n * esz,
-                                (size_t)n * esz, c.input_channels, hipMemcpyDeviceToDevice, s));
-    st->received += n;
-    const int x_prev = st->x_valid, o_prev = st->o_valid;
-    const int x_valid = flush ? st->received : std::max(st->received - 2, 0);
-    const int o_valid = flush ? st->received : std::max(x_valid - 2, 0);
-    if (first_final) *first_final = o_prev;
-    if (num_final) *num_final = o_valid - o_prev;
-    if (flush) st->finished = true;
-    const int r0 = x_prev / 16 * 16, r1 = round_up(x_valid, 16);          // rows of the residual stream to (re)compute
-    const int g0 = f_prev / 16 * 16, g1 = round_up(st->received, 16);      // rows whose features changed
-    const int o0 = o_prev / 16 * 16, o1 = round_up(o_valid, 16);          // posterior rows
-    st->x_valid = x_valid; st->o_valid = o_valid;
+    const unsigned slot_index = st->step++ % PpgStream::kSlots;
+    char* stage = st->staging + (size_t)slot_index * tb.bytes;
+    HIP_OK(hipEventSynchronize(st->uploaded[slot_index]));               // (its last use, kSlots steps ago, is long done)
+    PpgWindow* win = reinterpret_cast<PpgWindow*>(stage + tb.win);       // [0] linear launches, [1] out-conv, [2] gather
+    StreamItemMeta* meta = reinterpret_cast<StreamItemMeta*>(stage + tb.meta);
+    AttnItem* items = reinterpret_cast<AttnItem*>(stage + tb.items);
+    // the three row maps ([0] residual rows, [1] posterior rows, [2] gathered rows) are collected here and packed
+    // right behind the items in use: the step uploads what it filled, not the tables' capacity
+    std::vector<int>& maps = st->map_scratch;
+    maps.assign(3 * (size_t)tb.max_blocks, 0);
+    int nmap[3] = {0, 0, 0}, nitems = 0, max_count = 0;
+    const int tile = e->head_dim == 128 ? ppg::attn_query_tile(e->head_dim) / 2 : ppg::attn_query_tile(e->head_dim);
+    for (int b = 0; b < B; ++b) {
+        const int n = counts[b];
+        const bool fl = flush && flush[b];
+        const bool active = n > 0 || fl;
+        const int f_prev = st->received[b], x_prev = st->x_valid[b], o_prev = st->o_valid[b];
+        if (active) st->received[b] += n;
+        const int x_new = !active ? x_prev : (fl ? st->received[b] : std::max(st->received[b] - 2, 0));
+        const int o_new = !active ? o_prev : (fl ? st->received[b] : std::max(x_new - 2, 0));
+        if (first_final) first_final[b] = o_prev;
+        if (num_final) num_final[b] = o_new - o_prev;
+        if (fl) st->finished[b] = 1;
+        st->x_valid[b] = x_new; st->o_valid[b] = o_new;
+        // the item's window as the three kinds of launch see it
+        PpgWindow w{};
+        w.item = b; w.chunked = 0; w.start = 0; w.frames = R; w.valid = x_new;
+        w.keep_lo = 0; w.keep_hi = R; w.out_frame = 0; w.vt_off = b * R; w.tok_off = b * R;
+        win[b] = w;
+        win[B + b] = w; win[B + b].frames = fl ? st->received[b] : R;    // out-conv: zero padding at the true end once it is known
+        win[2 * B + b] = w;
+        meta[b] = StreamItemMeta{b * R, f_prev, active ? n : 0, 0};
+        max_count = std::max(max_count, meta[b].count);
+        if (!active) continue;
+        const int r0 = x_prev / 16 * 16, r1 = round_up(x_new, 16);          // rows of the residual stream to (re)compute
+        const int g0 = f_prev / 16 * 16, g1 = round_up(st->received[b], 16);  // rows whose features changed
+        const int o0 = o_prev / 16 * 16, o1 = round_up(o_new, 16);          // posterior rows
+        for (int r = r0; r < r1; r += 16) maps[nmap[0]++] = b * R + r;
+        for (int r = o0; r < o1; r += 16) maps[tb.max_blocks + nmap[1]++] = b * R + r;
+        for (int r = g0; r < g1; r += 16) maps[2 * tb.max_blocks + nmap[2]++] = b * R + r;
+        for (int q0 = r0 / tile * tile; q0 < r1; q0 += tile) {
+            if (nitems == tb.max_items) return fail(PPG_EINVAL, "more than %d query tiles in one step", tb.max_items);
+            items[nitems++] = AttnItem{b, q0, b * R, b * R, R, x_new, e->head_dim == 128 ? 1 : 0, 0};
+        }
+    }
+    size_t map_off[3], used = align_up(tb.items + (size_t)nitems * sizeof(AttnItem), 64);
+    for (int k = 0; k < 3; ++k) {
+        const int padded = round_up(nmap[k], 4);                           // unused wave slots of the last workgroup: nothing to do
+        for (int i = nmap[k]; i < padded; ++i) maps[k * tb.max_blocks + i] = MT;
+        map_off[k] = used;
+        memcpy(stage + used, maps.data() + (size_t)k * tb.max_blocks, (size_t)padded * sizeof(int));
+        used = align_up(used + (size_t)padded * sizeof(int), 64);
+    }
+    HIP_OK(hipMemcpyAsync(st->d_tables, stage, used, hipMemcpyHostToDevice, s));
+    const PpgWindow* d_win = reinterpret_cast<const PpgWindow*>(st->d_tables + tb.win);
+    const StreamItemMeta* d_meta = reinterpret_cast<const StreamItemMeta*>(st->d_tables + tb.meta);
+    const AttnItem* d_items = reinterpret_cast<const AttnItem*>(st->d_tables + tb.items);
 
 #define LAUNCH_OK(expr, what)                                                        \
     do {                                                                             \
@@ -1465,124 +1573,115 @@ int ppg_stream_push(PpgStream* st, const void* chunk, int n, int flush, int soft
         if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
     } while (0)
 
+    if (max_count > 0) {
+        const int per_item = c.input_channels * max_count;
+        hipLaunchKernelGGL(stream_append_kernel, dim3((per_item + 255) / 256, B), dim3(256), 0, s,
+                           d_meta, static_cast<const char*>(chunk), nmax, c.input_channels, R, esz, st->feats);
+        LAUNCH_OK(hipGetLastError(), "stream append");
+    }
     char* base = st->buf;
     const Workspace& ws = st->ws;
     char* xw = base + ws.xw;
     float* X = reinterpret_cast<float*>(base + ws.x);
     char* Xb = e->sz == 2 ? base + ws.xb : nullptr;
     char* ao = base + ws.ao;
-    float* part = reinterpret_cast<float*>(base + ws.total);
     auto qk_of = [&](int l) { return base + st->cache_off + (size_t)l * (st->qk_bytes + st->vt_bytes); };
     auto vt_of = [&](int l) { return qk_of(l) + st->qk_bytes; };
     const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
-    const size_t xrow = (size_t)H * e->sz;
 
-    // the window as the launches of a row range [row0, ..) see it
-    PpgWindow w{};
-    w.item = 0; w.chunked = 0; w.start = 0; w.frames = R; w.valid = x_valid;
-    w.keep_lo = 0; w.keep_hi = R; w.out_frame = 0; w.vt_off = 0;
-    const unsigned slot_index = st->step++ % PpgStream::kSlots;
-    PpgStream::Staging& stage = st->staging[slot_index];
-    HIP_OK(hipEventSynchronize(st->uploaded[slot_index]));               // (its last use, kSlots steps ago, is long done)
-    auto upload_window = [&](int slot, int row0, int frames_seen) -> int {
-        PpgWindow& v = stage.win[slot];
-        v = w;
-        v.tok_off = -row0;
-        v.frames = frames_seen;
-        HIP_OK(hipMemcpyAsync(st->d_win + slot, &v, sizeof(v), hipMemcpyHostToDevice, s));
-        return PPG_OK;
-    };
-    int rc;
-    if (g1 > g0) {
-        if ((rc = upload_window(2, g0, R))) return rc;
+    if (nmap[2] > 0) {
         GatherArgs g{};
         g.feats = st->feats; g.dtype = st->dtype; g.C = c.input_channels; g.T = R; g.overlap = c.chunk_overlap;
-        g.xw = xw + (size_t)g0 * e->Cp * e->sz; g.Cp = e->Cp;
-        g.blk_win = st->d_blk; g.win = st->d_win + 2; g.M = g1 - g0;
-        g.vt = vt_of(0); g.vt_ld = ws.vt_ld; g.vt_rows = H; g.vt_tokens = R; g.nwin = 0;     // (no window tails to clear: R is a multiple of 32; the caches were zeroed at creation)
-        g.qk_slack = qk_of(0) + (size_t)R * 2 * H * e->sz; g.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
+        g.xw = xw; g.Cp = e->Cp;
+        g.blk_win = st->d_blk; g.win = d_win + 2 * B; g.M = MT;
+        g.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[2]); g.map_blocks = nmap[2];
+        g.vt = vt_of(0); g.vt_ld = ws.vt_ld; g.vt_rows = H; g.vt_tokens = MT; g.nwin = 0;     // (no window tails to clear: R is a multiple of 32; the caches were zeroed at creation)
+        g.qk_slack = qk_of(0) + (size_t)MT * 2 * H * e->sz; g.qk_slack_bytes = (int)(64 * 2 * H * e->sz);
         LAUNCH_OK(ppg::launch_gather(prec, g, s), "stream gather");
     }
-    if (r1 > r0) {
-        const int M = r1 - r0;
-        if ((rc = upload_window(0, r0, R))) return rc;
-        const int lnt = 1;
+    if (nmap[0] > 0) {
         auto base_args = [&]() {
             LinearArgs a{};
-            a.blk_win = st->d_blk; a.win = st->d_win; a.M = M; a.H = H;
-            a.X = X + (size_t)r0 * H; a.Xb = Xb ? Xb + (size_t)r0 * H * 2 : nullptr; a.v_start = INT_MAX; a.taps = 1;
+            a.blk_win = st->d_blk; a.win = d_win; a.M = MT; a.H = H;
+            a.X = X; a.Xb = Xb; a.v_start = INT_MAX; a.taps = 1;
+            a.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[0]); a.map_blocks = nmap[0];
             return a;
         };
         {
             LinearArgs a = base_args();
-            a.act = xw + (size_t)r0 * e->Cp * e->sz; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
+            a.act = xw; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
             a.groups_per_tap = e->in_groups_per_tap; a.real_groups = 5 * e->in_groups_per_tap;
             a.total_groups = e->in_total_groups;
             a.W = e->w_in; a.bias = e->b_in; a.N = H; a.pe = e->pe;
-            LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, lnt, a, H / 256, s), "stream in-conv");
+            LAUNCH_OK(ppg::launch_linear(prec, EPI_INCONV, 16, 1, a, H / 256, s), "stream in-conv");
         }
-        // attention items: query tiles that cover [r0, r1)
-        const int qt = ppg::attn_query_tile(e->head_dim), tile = e->head_dim == 128 ? qt / 2 : qt;
-        int nitems = 0;
-        for (int q0 = r0 / tile * tile; q0 < r1; q0 += tile) {
-            if (nitems == PpgStream::kMaxItems) return fail(PPG_EINVAL, "a step of %d rows needs more than %d query tiles", M, PpgStream::kMaxItems);
-            stage.items[nitems++] = AttnItem{0, q0, 0, 0, R, x_valid, e->head_dim == 128 ? 1 : 0, 0};
-        }
-        HIP_OK(hipMemcpyAsync(st->d_items, stage.items, nitems * sizeof(AttnItem), hipMemcpyHostToDevice, s));
-        int nt = 1, splits = 1;
-        choose_ffn_tiling(e, M, &nt, &splits);
-        if (nt == ppg::kFfnMixedTiling) nt = 1;
         const int hg = H / e->KG;
+        // hidden splits: as many workgroups per token tile as fill the chip (each streams its share of W1 / W2)
+        int ffn_splits = 1;
+        if (e->ffn_split) {
+            const int wgs = (nmap[0] + 3) / 4;
+            const int cap = e->ffn_split_max > 0 ? std::min(e->ffn_split_max, st->max_splits) : st->max_splits;
+            while (ffn_splits * 2 <= cap && wgs * ffn_splits * 2 <= e->num_cus) ffn_splits *= 2;
+        }
         for (int l = 0; l < c.num_layers; ++l) {
             const DevLayer& d = e->layers[l];
             char* qk = qk_of(l);
             char* vt = vt_of(l);
             {
                 LinearArgs a = base_args();
-                a.act = act_x + (size_t)r0 * xrow; a.lda_bytes = H * e->sz;
+                a.act = act_x; a.lda_bytes = H * e->sz;
                 a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
                 a.W = d.wqkv; a.bias = d.bqkv; a.N = 3 * H;
-                a.out_rows = qk + (size_t)r0 * 2 * H * e->sz; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
-                LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, lnt, a, 3 * H / 256, s), "stream qkv");
+                a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = ws.vt_ld; a.v_start = 2 * H;
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, 1, a, 3 * H / 256, s), "stream qkv");
             }
             {
                 AttnArgs a{};
                 a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
                 a.ao = ao; a.H = H; a.causal = 1;
-                a.items = st->d_items; a.win = st->d_win; a.M = R; a.ao_tiled = 0; a.heads = c.heads;
+                a.items = d_items; a.win = d_win; a.M = MT; a.ao_tiled = 0; a.heads = c.heads;
                 LAUNCH_OK(ppg::launch_attn(prec, a, nitems, c.heads, e->head_dim, s), "stream attention");
             }
             {
                 LinearArgs a = base_args();
-                a.act = ao + (size_t)r0 * xrow; a.lda_bytes = H * e->sz;
+                a.act = ao; a.lda_bytes = H * e->sz;
                 a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
                 a.W = d.wo; a.bias = d.bo; a.N = H; a.gamma = d.g1; a.beta = d.e1;
                 LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, 1, a, 1, s), "stream out-proj+LN");
             }
             {
                 FfnArgs a{};
-                a.X = X + (size_t)r0 * H; a.Xb = Xb ? Xb + (size_t)r0 * H * 2 : nullptr;
+                a.X = X; a.Xb = Xb;
                 a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
-                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M;
-                a.splits = splits; a.partial = splits > 1 ? part : nullptr;
-                LAUNCH_OK(ppg::launch_ffn(prec, a, nt, s), "stream ffn");
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = MT;
+                a.splits = ffn_splits; a.partial = ffn_splits > 1 ? reinterpret_cast<float*>(base + st->part_off) : nullptr;
+                a.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[0]); a.map_blocks = nmap[0];
+                LAUNCH_OK(ppg::launch_ffn(prec, a, 1, s), "stream ffn");
             }
         }
     }
-    if (o1 > o0) {
-        if ((rc = upload_window(1, o0, flush ? st->received : R))) return rc;
+    if (nmap[1] > 0) {
         LinearArgs a{};
-        a.blk_win = st->d_blk; a.win = st->d_win + 1; a.M = o1 - o0; a.H = H; a.v_start = INT_MAX;
-        a.act = act_x + (size_t)o0 * xrow; a.lda_bytes = H * e->sz; a.taps = 5;
+        a.blk_win = st->d_blk; a.win = d_win + B; a.M = MT; a.H = H; a.v_start = INT_MAX;
+        a.act = act_x; a.lda_bytes = H * e->sz; a.taps = 5;
         a.groups_per_tap = e->out_groups_per_tap; a.real_groups = 5 * e->out_groups_per_tap;
         a.total_groups = e->out_total_groups;
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = st->probs; a.out_T = R; a.out_C = c.output_channels; a.softmax = softmax;
+        a.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[1]); a.map_blocks = nmap[1];
         LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, 1, a, 1, s), "stream out-conv+softmax");
     }
 #undef LAUNCH_OK
     HIP_OK(hipEventRecord(st->uploaded[slot_index], s));
     return PPG_OK;
+}
+
+int ppg_stream_push(PpgStream* st, const void* chunk, int n, int flush, int softmax,
+                    int* first_final, int* num_final, void* stream_) {
+    if (!st || st->batch != 1) return fail(PPG_EINVAL, "ppg_stream_push is the one-utterance form (use ppg_stream_push_batch)");
+    if (n < 0 || (n > 0 && !chunk)) return fail(PPG_EINVAL, "bad argument");
+    if (st->finished[0]) return fail(PPG_EINVAL, "the stream was flushed");
+    return ppg_stream_push_batch(st, chunk, n, &n, &flush, softmax, first_final, num_final, stream_);
 }
 
 // ----------------------------------------------------------------------------

@@ -301,8 +301,10 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     const int c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 63;   // token within tile (read phase)
     const int ty = threadIdx.x >> 6;   // 0..3
+    // token row of tile position tl (row map: every 16-row block of the tile has its own place)
+    auto row_of = [&](int tl) { return a.rowmap ? a.rowmap[blockIdx.x * 4 + (tl >> 4)] + (tl & 15) : tok0 + tl; };
     {
-        const int m = tok0 + tx;
+        const int m = row_of(tx);
         const TokMeta tm = tok_meta(a.blk_win, a.win, m, a.M);
         int frame = -1;
         size_t base = 0;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int tl = tq * 8 + i;
-            const int m = tok0 + tl;
+            const int m = row_of(tl);
             if (m < a.M && c0 + c < a.Cp) {
                 const float v = tile[c][tl];
                 typename P::elem* dst = reinterpret_cast<typename P::elem*>(a.xw) + (size_t)m * a.Cp + c0 + c;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15;
     const int g = lane >> 4;
-    const int tok0 = (blockIdx.x * 4 + wave) * 16 * NT;
+    const int tok0 = a.rowmap ? __builtin_amdgcn_readfirstlane(a.rowmap[blockIdx.x * 4 + wave]) : (blockIdx.x * 4 + wave) * 16 * NT;
     const int n0 = blockIdx.y * NB * 16;
     const bool swap = (EPI == EPI_QKV) && (n0 >= a.v_start);
 
@@ -771,7 +773,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
     // starting at its own offset, so that the CUs of one XCD (b, b+8, b+16, ...)
     // do not all pull the same 64 KiB of weights through the same L2 lines at
     // the same moment.
-    const int rot = (blockIdx.x >> 3) % NC;
+    const int rot = a.rowmap ? 0 : (blockIdx.x >> 3) % NC;     // (row map = streaming: a recomputed row must give the same bits wherever it lands)
     auto hidden_chunk = [&](int c) { const int r = c + rot; return c_base + (r >= NC ? r - NC : r); };
     auto stage_w1 = [&](int c) {
         stage_tile<HC, ROW1, 4>(a.W1 + (size_t)hidden_chunk(c) * 32768, (size_t)ROW1, smem + (c & 1) * 32768, wave, lane);
@@ -1052,15 +1054,19 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
 
     pstamp(9);
     if (a.partial != nullptr) {
-        // split-hidden: raw partial sums, [split][token][feature] fp32
-        float* part = a.partial + (size_t)blockIdx.y * a.M * H;
+        // split-hidden: raw partial sums, [split][token][feature] fp32.  Under a row map the rows are those of the
+        // launch's slots, densely (the step's rows lie all over the token space: a split stride of the whole space put
+        // every 16-row block of every split on a page of its own -- 30 us of address translation in the reduce pass)
+        const int prows = a.rowmap ? (int)gridDim.x * 64 : a.M;
+        float* part = a.partial + (size_t)blockIdx.y * prows * H;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int m = tok0 + 16 * t + idx;
             if (m >= a.M) continue;
+            const int pm = a.rowmap ? (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + idx : m;
 #pragma unroll
             for (int nb = 0; nb < NBH; ++nb)
-                *reinterpret_cast<float4*>(part + (size_t)m * H + pair_feature(nb, g)) =
+                *reinterpret_cast<float4*>(part + (size_t)pm * H + pair_feature(nb, g)) =
                     make_float4(yacc[nb][t][0], yacc[nb][t][1], yacc[nb][t][2], yacc[nb][t][3]);
         }
         return;
@@ -1219,7 +1225,8 @@ template <class P, int NT, int NBH, bool OP, bool QKV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    ffn_body<P, NT, NT, NBH, OP, QKV, 0>(a, smem, (blockIdx.x * 4 + wave) * 16 * NT);
+    const int tok0 = a.rowmap ? __builtin_amdgcn_readfirstlane(a.rowmap[blockIdx.x * 4 + wave]) : (blockIdx.x * 4 + wave) * 16 * NT;
+    ffn_body<P, NT, NT, NBH, OP, QKV, 0>(a, smem, tok0);
 }
 
 // Mixed tiling: 160 tokens per workgroup = waves owning 3, 3, 2, 2 blocks of 16,
@@ -1242,7 +1249,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <class P>
 __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int splits) {
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = a.rowmap ? a.rowmap[slot >> 4] + (slot & 15) : slot;          // (row map: only the rows of the step)
     if (m >= a.M) return;
     const int H = a.H;
     float4 v[2];
@@ -1254,8 +1262,8 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
         float4 acc = make_float4(bv.x + xv.x, bv.y + xv.y, bv.z + xv.z, bv.w + xv.w);
         // the partial sums are added in split order, loaded 8 / 4 / 1 at a time:
         // one load latency per batch instead of one per split
-        const float* part = a.partial + (size_t)m * H + n;
-        const size_t stride = (size_t)a.M * H;
+        const float* part = a.partial + (size_t)(a.rowmap ? slot : m) * H + n;
+        const size_t stride = (size_t)(a.rowmap ? (a.map_blocks + 3) / 4 * 64 : a.M) * H;
         int sidx = 0;
         auto batch = [&](auto count) {
             constexpr int N = decltype(count)::value;
@@ -1618,7 +1626,8 @@ __global__ __launch_bounds__(256, 2) void attn_mixed_kernel(AttnArgs a) {
 
 template <class P, int NT, int NB, int EPI>
 hipError_t launch_linear_t(const LinearArgs& a, int ypasses, hipStream_t s) {
-    const int blocks = (a.M + 64 * NT - 1) / (64 * NT);
+    if (a.rowmap && NT != 1) return hipErrorInvalidValue;
+    const int blocks = a.rowmap ? (a.map_blocks + 3) / 4 : (a.M + 64 * NT - 1) / (64 * NT);
     const size_t lds = 2 * NB * 16 * 128;
     auto kern = linear_kernel<P, NT, NB, EPI>;
     if (lds > 65536) {
@@ -1657,7 +1666,8 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
 
 template <class P, int NT, int NBH, bool OP, bool QKV>
 hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
-    const dim3 blocks((a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
+    if (a.rowmap && NT != 1) return hipErrorInvalidValue;
+    const dim3 blocks(a.rowmap ? (a.map_blocks + 3) / 4 : (a.M + 64 * NT - 1) / (64 * NT), a.partial ? a.splits : 1);
     auto kern = ffn_kernel<P, NT, NBH, OP, QKV>;
     const size_t lds = 131072 + (size_t)a.F * 4 + ((OP || QKV) ? 9 : 6) * (size_t)a.H * 4;   // b1, [b2 g2 e2], [bq], [bo g1 e1]
     static ppg::LdsLimit limit;
@@ -1666,7 +1676,7 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, blocks, dim3(256), lds, s, a);
     e = hipGetLastError();
     if (e != hipSuccess || !a.partial) return e;
-    hipLaunchKernelGGL(ffn_reduce_ln_kernel<P>, dim3((a.M + 3) / 4), dim3(256), 0, s, a, a.splits);
+    hipLaunchKernelGGL(ffn_reduce_ln_kernel<P>, dim3(a.rowmap ? a.map_blocks * 4 : (a.M + 3) / 4), dim3(256), 0, s, a, a.splits);
     return hipGetLastError();
 }
 
@@ -1739,7 +1749,7 @@ int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }   // (d
 #endif
 
 hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s) {
-    dim3 grid((a.M + 63) / 64, (a.Cp + 31) / 32 + 1);       // + the housekeeping row
+    dim3 grid(a.rowmap ? (a.map_blocks + 3) / 4 : (a.M + 63) / 64, (a.Cp + 31) / 32 + 1);       // + the housekeeping row
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(gather_kernel<PrecBF16>, grid, dim3(256), 0, s, a);
 #if PPG_OTHER_PRECISIONS
     else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(gather_kernel<PrecF16>, grid, dim3(256), 0, s, a);

@@ -141,6 +141,12 @@ SYMBOLS = {
     'ppg_stream_push': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    'ppg_stream_create_batch': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'ppg_stream_batch': (ctypes.c_int, [ctypes.c_void_p]),
+    'ppg_stream_push_batch': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+        ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     'ppg_w2v2_create': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'ppg_w2v2_destroy': (None, [ctypes.c_void_p]),
@@ -323,6 +329,11 @@ class Engine:
         """A KV-cached causal stream over one utterance of up to `max_frames` frames
         (see Stream); the engine must be causal."""
         return Stream(self, max_frames, dtype)
+
+    def batched_stream(self, batch, max_frames, dtype=torch.float16):
+        """KV-cached causal streams over `batch` utterances advanced together (see
+        BatchedStream); the engine must be causal."""
+        return BatchedStream(self, batch, max_frames, dtype)
 
     def long_stream(self, dtype=torch.float16):
         """A KV-cached causal stream over an utterance of any length > 500 frames
@@ -621,6 +632,74 @@ class Stream:
                 address = self._lib.ppg_stream_posteriors(self._handle)
                 source = _device_view(address, (engine.output_channels, self.rows), engine.device)
                 out.copy_(source[:, first.value:first.value + count.value])
+        return out
+
+
+class BatchedStream:
+    """KV-cached streaming causal inference for `batch` utterances advanced together (ppg_stream_create_batch /
+    ppg_stream_push_batch): configs[4] of the reference -- causal_transformer, streaming chunks, batch = 64 -- with
+    the state the reference does not keep.  Item b is an utterance of its own (one window, <= 500 frames) with its
+    own frontier: a push hands every item its own number of new frames (ragged, not aligned to anything, 0 = the
+    item sits this step out) and ONE launch sequence advances them all.  Each item equals the causal forward of
+    its whole utterance, like :class:`Stream`."""
+
+    def __init__(self, engine, batch, max_frames, dtype=torch.float16):
+        if dtype not in (torch.float16, torch.float32):
+            raise ValueError('stream features are fp16 or fp32')
+        self.engine, self.dtype, self.batch = engine, dtype, int(batch)
+        self._lib = engine._lib
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(engine.device):
+            _check(self._lib.ppg_stream_create_batch(
+                engine._handle, self.batch, int(max_frames), 0 if dtype == torch.float16 else 1,
+                ctypes.byref(handle)))
+        self._handle = handle
+        rows = ctypes.c_int()
+        _check(self._lib.ppg_stream_rows(self._handle, ctypes.byref(rows), None, None))
+        self.rows = rows.value
+        self.max_frames = int(max_frames)
+        self.received = [0] * self.batch
+        address = self._lib.ppg_stream_posteriors(self._handle)
+        self._posteriors = _device_view(
+            address, (self.batch, engine.output_channels, self.rows), engine.device)
+
+    def __del__(self):
+        handle, self._handle = getattr(self, '_handle', None), None
+        if handle:
+            self._lib.ppg_stream_destroy(handle)
+
+    def push(self, chunks, counts=None, flush=False, softmax=True):
+        """chunks (batch, input_channels, n_max) on the engine's GPU (or None with only flushes), counts[b] <= n_max
+        new frames of item b (default: n_max for every item), flush: bool or one bool per item -> a list of
+        (40, k_b) fp32 tensors: the posteriors of item b's frames that became final with this step, in order."""
+        engine = self.engine
+        if chunks is None:
+            chunks = torch.empty(self.batch, engine.input_channels, 0, dtype=self.dtype, device=engine.device)
+        if chunks.dim() != 3 or chunks.shape[0] != self.batch or chunks.shape[1] != engine.input_channels:
+            raise ValueError(f'chunks must be ({self.batch}, {engine.input_channels}, frames), got {tuple(chunks.shape)}')
+        chunks = chunks.to(device=engine.device, dtype=self.dtype).contiguous()
+        nmax = chunks.shape[2]
+        counts = [nmax] * self.batch if counts is None else [int(n) for n in counts]
+        flushes = [bool(flush)] * self.batch if isinstance(flush, bool) else [bool(f) for f in flush]
+        if len(counts) != self.batch or len(flushes) != self.batch:
+            raise ValueError('counts / flush need one entry per item')
+        array = ctypes.c_int * self.batch
+        first, final = array(), array()
+        with torch.cuda.device(engine.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(self._lib.ppg_stream_push_batch(
+                self._handle, ctypes.c_void_p(chunks.data_ptr()), nmax, array(*counts),
+                array(*[int(f) for f in flushes]), int(softmax), first, final, ctypes.c_void_p(stream)))
+            # ONE copy (ordered behind the step on the current stream; the stream object owns the source): the column
+            # range all newly final frames lie in, of every item; the results are views of it
+            spans = [(first[b], first[b] + final[b]) for b in range(self.batch) if final[b] > 0]
+            lo = min((a for a, _ in spans), default=0)
+            hi = max((b for _, b in spans), default=0)
+            block = self._posteriors[:, :, lo:hi].clone()
+            out = [block[b, :, first[b] - lo:first[b] - lo + final[b]] if final[b] > 0 else block[b, :, :0]
+                   for b in range(self.batch)]
+        for b in range(self.batch):
+            self.received[b] += counts[b]
         return out
 
 

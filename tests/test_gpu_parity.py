@@ -1199,3 +1199,46 @@ def test_c4_thousand_utterances_slice():
         for row, index in enumerate(keep):
             err = np.abs(out[index].numpy() - ref[row, :, :frames[index]]).max()
             assert err < FP32_TOL, (index, err)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_batched_kv_cached_streams_equal_causal_forward(precision):
+    """Several utterances advanced together by ONE launch sequence per step (engine.batched_stream: row-mapped
+    launches of the token-split kernels, one attention launch over all items' query tiles): every item equals
+    the oracle's causal forward of its own utterance, with ragged, unaligned pushes per item, items that sit
+    steps out, items that end at different steps and an item of one frame."""
+    engine, state = eng(precision=precision, causal=True)
+    gen = torch.Generator().manual_seed(91)
+    totals = [437, 160, 1, 500, 33, 275, 96]
+    batch = len(totals)
+    feats = [torch.randn(80, n, generator=gen).half() for n in totals]
+    ref = [O.from_features(state, f[None].float(), torch.tensor([n]), is_causal=True).numpy()[0] for f, n in zip(feats, totals)]
+    stream = engine.batched_stream(batch, 500)
+    sent, pieces, done = [0] * batch, [[] for _ in range(batch)], [False] * batch
+    sizes = [16, 48, 7, 100, 1, 64, 33, 90, 2, 76, 130, 49, 5]
+    step = 0
+    while not all(done):
+        counts, flush = [], []
+        for b in range(batch):
+            n = 0 if done[b] or (step + b) % 5 == 4 else min(sizes[(step + 3 * b) % len(sizes)], totals[b] - sent[b])
+            counts.append(n)
+            flush.append(not done[b] and sent[b] + n == totals[b] and (n > 0 or sent[b] == totals[b]))
+        nmax = max(counts)
+        chunk = torch.zeros(batch, 80, nmax, dtype=torch.float16)
+        for b in range(batch):
+            chunk[b, :, :counts[b]] = feats[b][:, sent[b]:sent[b] + counts[b]]
+        out = stream.push(chunk.cuda(), counts, flush)
+        for b in range(batch):
+            sent[b] += counts[b]
+            pieces[b].append(out[b])
+            done[b] = done[b] or flush[b]
+            assert sum(p.shape[1] for p in pieces[b]) <= (sent[b] if done[b] else max(sent[b] - 4, 0))
+        step += 1
+        assert step < 400
+    tol = FP32_TOL if precision == 'fp32' else 2e-3
+    for b in range(batch):
+        got = torch.cat(pieces[b], dim=1).cpu().numpy()
+        assert got.shape == (40, totals[b])
+        assert np.abs(got - ref[b]).max() < tol, b
+    with pytest.raises(ValueError):
+        stream.push(torch.zeros(batch, 80, 4).cuda(), [4] * batch)        # every item was flushed

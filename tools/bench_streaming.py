@@ -78,6 +78,28 @@ def main():
         return {'frames_per_push': n, 'median_us': times[len(times) // 2] * 1e6, 'p90_us': times[int(len(times) * 0.9)] * 1e6,
                 'pushes_timed': len(times)}
     kv = [stream_latency(n) for n in (16, 48, 160)]
+
+    # the same for `batch` utterances advanced together (ppg_stream_push_batch: ONE launch sequence per step)
+    def batched_latency(n):
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(2):
+            stream = model.batched_stream(args.batch, 500)
+            chunk = torch.randn(args.batch, 80, n, generator=generator).half().cuda()
+            received = 0
+            while received + n <= 480:
+                torch.cuda.synchronize()
+                start = time.perf_counter()
+                stream.push(chunk)
+                torch.cuda.synchronize()
+                if received >= 200:
+                    times.append(time.perf_counter() - start)
+                received += n
+        times.sort()
+        return {'streams': args.batch, 'frames_per_push': n, 'median_us': times[len(times) // 2] * 1e6,
+                'p90_us': times[int(len(times) * 0.9)] * 1e6, 'pushes_timed': len(times),
+                'frames_per_s': args.batch * n / times[len(times) // 2]}
+    kvb = [batched_latency(n) for n in (16, 48, 160)]
     per_step = args.batch * args.frames
     # single 160-frame windows: 13 414 400 FLOP per frame + 5120 Tc^2 per window (causal
     # attention computes about half of the Tc^2 term)
@@ -94,8 +116,11 @@ def main():
         'end_to_end_tflops': flops / graphed / 1e12,
         'kernel_ms_per_step': kernels,
         'kv_cached_stream': {'what': 'one utterance, K / V^T and residual rows of all layers cached on the device, 14 + 4 x 5 '
-                                     'launches per push on row ranges of the token-split kernels; wall time of push() + synchronize', 'steps': kv},
-        'roofline': {'kernel': 'layer kernel launches (10 240 token rows: token-split, hidden chunks split over workgroups)',
+                                     'launches per push on row-mapped launches of the token-split kernels; wall time of push() + synchronize', 'steps': kv},
+        'kv_cached_batched_stream': {'what': f'{args.batch} utterances advanced together, each with its own K / V^T cache and frontier: ONE '
+                                             'launch sequence (24 launches) per step for all of them; wall time of push() + synchronize '
+                                             '(includes the per-item result copies)', 'steps': kvb},
+        'roofline': {'kernel': 'layer kernel launches (10 240 token rows: layer32 kernel, sub-tile workgroups of two token blocks)',
                      'bound': 'mfma', 'achieved': layer_flops / layer_ms / 1e9, 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': layer_flops / layer_ms / 1e9 / peak, 'mean_launch_ms': layer_ms},
     }))
