@@ -41,6 +41,11 @@ enum {
                                same MFMA rate as bf16, ~8x smaller operand rounding;
                                operands must stay below 65504 in magnitude (what the
                                reference's CUDA autocast assumes, ppgs/core.py:586)  */
+    PPG_PRECISION_FP16X2 = 3, /* fp32 values as two fp16 halves (hi + lo), a product as three fp16 MFMAs with
+                               fp32 accumulation: fp32-grade operands (22 significand bits; <= 1e-4 vs the
+                               reference's fp32 forward -- the autocast-off route of ppgs/core.py:586-594)
+                               at a third of the fp16 MFMA rate, 5x the f32-input MFMA rate.  mel-sized
+                               models (hidden 256, head dimension 128); magnitudes below 65504 as fp16   */
 };
 
 /* dtype tags for feature tensors handed to ppg_encode */
@@ -381,6 +386,15 @@ int ppg_grid_sample(int device, const float* ppg, int rows, int frames,
  * ppg_engine_profile_stride(n): time only every n-th launch of each enabled
  * class (n = 1: all); `launches` then counts the timed ones.
  */
+/*
+ * Sticky non-finite flag.  The 16-bit operand modes assume activations inside the operand format's range (fp16:
+ * |x| < 65504 -- what the reference's own CUDA autocast assumes of its checkpoints); an overflow upstream (or
+ * non-finite input features) ends as NaN logits.  The output kernels set a device flag whenever a VALID frame's logit
+ * is not finite; ppg_engine_nonfinite copies it to *flag (synchronising with the device) and, with clear != 0,
+ * resets it.  The Python layer raises on it wherever it synchronises anyway (file pipelines, from_audio with
+ * PPGS_AMD_CHECK_FINITE=1) so that NaN posteriors never leave silently.
+ */
+int ppg_engine_nonfinite(PpgEngine* engine, int clear, int* flag);
 int ppg_engine_profile(PpgEngine* engine, int classes);
 int ppg_engine_profile_read(PpgEngine* engine, int kernel_class,
                             double* total_ms, int64_t* launches);

@@ -28,6 +28,7 @@ from . import config, data, engine, load, preprocess
 #   'bf16'  bf16 operands (the benchmark configuration of BASELINE.json; ~2-3e-3, which is what
 #           the reference's own bf16 autocast loses, fixture g7_glue)
 #   'fp32'  f32-input MFMA, the parity mode (<= 1e-4)
+CHECK_FINITE = os.environ.get('PPGS_AMD_CHECK_FINITE', '0') != '0'
 PRECISION = os.environ.get('PPGS_AMD_PRECISION', 'fp16')
 
 # Frame budget of one padded batch when the caller leaves max_frames at the
@@ -136,7 +137,9 @@ def from_file_to_file(audio_file, output_file,
     result = from_file(
         file=audio_file, checkpoint=checkpoint, representation=representation,
         gpu=gpu, legacy_mode=legacy_mode)
-    torch.save(result.detach().cpu(), output_file)
+    host = result.detach().cpu()
+    engine_for(representation, checkpoint, result.device.index).check_finite()     # (raises instead of saving NaNs)
+    torch.save(host, output_file)
 
 
 def from_files_to_files(audio_files, output_files,
@@ -277,6 +280,13 @@ def from_dataloader(dataloader, output_files,
         host, filenames, frame_lengths, keep = slot.job
         slot.done.synchronize()
         slot.job = None
+        # (the batch is complete on the device: a non-finite logit in it has set the engine's flag by now)
+        if engine_for(representation, checkpoint, device.index).nonfinite(clear=True):
+            warnings.warn(
+                f'Skipping a batch of {len(filenames)} files ({filenames[0]} ...): non-finite posteriors '
+                f'({PRECISION} operands out of range, or non-finite audio); PPGS_AMD_PRECISION=bf16 / fp32 '
+                'has the range of fp32')
+            return
         # the native writer emits torch.load-able (40, length) files, several
         # threads per batch, off the main thread
         if pool is not None:
@@ -331,8 +341,11 @@ def infer(features, lengths, representation='mel', checkpoint=None,
           softmax=True, legacy_mode=False):
     """Perform model inference (reference ppgs/core.py:551-596)."""
     model = engine_for(representation, checkpoint, features.device.index)
-    return model.encode(
+    out = model.encode(
         features, lengths, softmax=softmax, legacy_mode=legacy_mode)
+    if CHECK_FINITE:                   # (synchronises: off by default, the call is asynchronous like the reference's)
+        model.check_finite()
+    return out
 
 
 _side_streams = {}

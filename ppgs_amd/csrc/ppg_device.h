@@ -72,6 +72,8 @@ struct PrecBF16 {
     static constexpr int kBytes = 2;
     static constexpr int KG = 32;   // elements per 64-byte K-group
     static constexpr bool kIsBF16 = true;
+    static constexpr bool kSplit = false;
+    static __device__ __forceinline__ int row_byte(int n) { return n * 2; }      // byte offset of element n in its row
     static constexpr float kProbCeil = 1.0995116e12f;   // 2^40: attention re-bases its softmax shift above this (attn_body)
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
     static __device__ __forceinline__ uint16_t cvt1(float v) { return f32_to_bf16_rne(v); }
@@ -103,6 +105,8 @@ struct PrecF16 {
     static constexpr int kBytes = 2;
     static constexpr int KG = 32;
     static constexpr bool kIsBF16 = true;
+    static constexpr bool kSplit = false;
+    static __device__ __forceinline__ int row_byte(int n) { return n * 2; }
     static constexpr float kProbCeil = 1024.0f;         // 2^10 (fp16 ends at 2^16)
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
     static __device__ __forceinline__ uint16_t cvt1(float v) { return __builtin_bit_cast(uint16_t, (_Float16)v); }
@@ -129,6 +133,8 @@ struct PrecF32 {
     static constexpr int kBytes = 4;
     static constexpr int KG = 16;
     static constexpr bool kIsBF16 = false;
+    static constexpr bool kSplit = false;
+    static __device__ __forceinline__ int row_byte(int n) { return n * 4; }
     static constexpr float kProbCeil = 1.0995116e12f;
     static __device__ __forceinline__ uint32_t pack2(float, float) { return 0u; }   // never used: 32-bit layouts
     static __device__ __forceinline__ float cvt1(float v) { return v; }
@@ -153,10 +159,77 @@ struct PrecF32 {
     static __device__ __forceinline__ uint32_t relu2(uint32_t packed) { return packed; }   // never used: 32-bit layouts
 };
 
+// fp32 values as TWO fp16 halves, x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significand bits down to fp16's
+// subnormal floor of 6e-8 -- the matrix pipe keeps fp16 subnormals, tools/denorm_probe.hip), and a product as THREE
+// fp16 MFMAs with fp32 accumulation: a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped a_lo b_lo is 2^-22 of the
+// product).  Operand precision of fp32 at a third of the fp16 MFMA rate -- 5 x the rate of the f32-input MFMAs.
+// Layout: the byte arithmetic of the fp32 path (4 bytes per element, 64-byte K-groups of "16 elements"), but a PAIR of
+// K-groups holds 32 elements as [32 hi halves | 32 lo halves]: lane group g's 16 bytes of the first K-group are the
+// fp16 MFMA fragment of k-slots 8g .. 8g + 7 of the hi plane, of the second K-group the same slots of the lo plane.
+// Every MFMA call site walks K-groups in order and knows its index: an even K-group (hi of the LDS-side operand)
+// meets the register-side operand's hi AND lo fragment, an odd one (lo) its hi fragment only (mma_kg below).
+// Handovers between GEMMs inside a kernel (FFN h, attention P) and the V^T columns use the 16-bit path's slot
+// orders (8 slots per lane from two accumulator blocks), with both planes.
+struct PrecX2 {
+    typedef float elem;
+    static constexpr int kBytes = 4;
+    static constexpr int KG = 16;
+    static constexpr bool kIsBF16 = false;
+    static constexpr bool kSplit = true;
+    static constexpr float kProbCeil = 1024.0f;         // fp16 operands
+    // byte offset of element n (a multiple of 4 or 8) of a row: the hi plane of its 32-element block; lo is 64 further
+    static __device__ __forceinline__ int row_byte(int n) { return (n >> 5) * 128 + (n & 31) * 2; }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    // (a, b) -> packed fp16 pair of the hi plane and of the lo plane
+    static __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+        hi = pack_f16x2(a, b);
+        const f16x2 h = __builtin_bit_cast(f16x2, hi);
+        lo = pack_f16x2(a - (float)h[0], b - (float)h[1]);
+    }
+    static __device__ __forceinline__ float cvt1(float v) { return v; }   // (never used: elements are written through split2)
+    static __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma0(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mmac(f32x4& acc, const u32x4& a, const u32x4& b, const f32x4& c) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t relu2(uint32_t packed) { return relu_packed16(packed); }
+};
+
+// One MFMA step of a GEMM whose LDS-side operand fragment `w` belongs to K-group KGI and whose register-side operand
+// is the array x[K-group][token block] (see PrecX2).  SWAP: the register-side operand is the MFMA's A operand.
+// FIRST: 0 accumulate, 1 start from zero, 2 start from `c`.
+template <class P, int KGI, bool SWAP, int FIRST, int NKG, int NTT>
+__device__ __forceinline__ void mma_kg(f32x4& acc, const u32x4& w, const u32x4 (&x)[NKG][NTT], int t, const f32x4& c) {
+    auto one = [&](const u32x4& xv, int first) {
+        if (first == 1) { if constexpr (SWAP) P::mma0(acc, xv, w); else P::mma0(acc, w, xv); }
+        else if (first == 2) { if constexpr (SWAP) P::mmac(acc, xv, w, c); else P::mmac(acc, w, xv, c); }
+        else { if constexpr (SWAP) P::mma(acc, xv, w); else P::mma(acc, w, xv); }
+    };
+    if constexpr (!P::kSplit) {
+        one(x[KGI][t], FIRST);
+    } else if constexpr (KGI % 2 == 0) {
+        one(x[KGI][t], FIRST);
+        one(x[KGI + 1][t], 0);
+    } else {
+        static_assert(FIRST == 0, "a split GEMM starts on an even K-group");
+        one(x[KGI - 1][t], 0);
+    }
+}
+
 // Store 4 consecutive elements (fp32 values) as P::elem at dst (8/16 B aligned)
 template <class P>
 __device__ __forceinline__ void store4(void* dst, float a, float b, float c, float d) {
-    if constexpr (P::kIsBF16) {
+    if constexpr (P::kSplit) {       // dst = the hi plane's place of the 4 elements (row base + P::row_byte(n)); lo 64 bytes on
+        uint32_t h0, l0, h1, l1;
+        P::split2(a, b, h0, l0);
+        P::split2(c, d, h1, l1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(static_cast<char*>(dst) + 64) = make_uint2(l0, l1);
+    } else if constexpr (P::kIsBF16) {
         *reinterpret_cast<uint2*>(dst) = make_uint2(P::pack2(a, b), P::pack2(c, d));
     } else {
         *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
@@ -182,9 +255,18 @@ __device__ __forceinline__ int pair_feature(int nb, int g) {   // first of the l
 // dst8 = address of feature 32p + 8g.  bf16: one 16-byte store at e = 1.
 template <class P>
 struct PairStore {
-    uint32_t lo0, lo1;
+    uint32_t lo0, lo1, sl0, sl1;
     __device__ __forceinline__ void put(void* dst8, int e, float a, float b, float c, float d) {
-        if constexpr (P::kIsBF16) {
+        if constexpr (P::kSplit) {   // dst8 = the hi plane's place of feature 32p + 8g (row base + P::row_byte(n & ~7))
+            uint32_t h0, l0, h1, l1;
+            P::split2(a, b, h0, l0);
+            P::split2(c, d, h1, l1);
+            if (e == 0) { lo0 = h0; lo1 = h1; sl0 = l0; sl1 = l1; }
+            else {
+                *reinterpret_cast<u32x4*>(dst8) = u32x4{lo0, lo1, h0, h1};
+                *reinterpret_cast<u32x4*>(static_cast<char*>(dst8) + 64) = u32x4{sl0, sl1, l0, l1};
+            }
+        } else if constexpr (P::kIsBF16) {
             if (e == 0) { lo0 = P::pack2(a, b); lo1 = P::pack2(c, d); }
             else *reinterpret_cast<u32x4*>(dst8) = u32x4{lo0, lo1, P::pack2(a, b), P::pack2(c, d)};
         } else {
@@ -287,6 +369,8 @@ struct LinearArgs {
     int act_y_stride;         // bytes added to `act` per blockIdx.y (grouped convolution: group y reads its own channels)
     const int* rowmap;        // see GatherArgs (16 tokens per wave only)
     int map_blocks;
+    unsigned* overflow;       // EPI_OUTCONV: bit 0 is set when a logit of a valid frame is not finite (fp16 operands past
+                              // 65504 upstream, non-finite input features ...): the engine's sticky flag, or null
 };
 
 struct FfnArgs {

@@ -50,6 +50,9 @@ uint16_t host_bf16(float f) {
 uint16_t host_f16(float f) {
     return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
+float host_f16_to_f32(uint16_t h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
 
 // ----------------------------------------------------------------------------
 // Chunk planner (reference ppgs/model/transformer.py:49-64)
@@ -230,10 +233,11 @@ struct DevPlan {
     hipEvent_t uploaded = nullptr;   // recorded behind the asynchronous upload of the tables
     hipStream_t upload_stream = nullptr;
     bool upload_done = false;
+    std::vector<hipStream_t> users;  // every stream a launch reading the tables was queued on (encodes run on several)
     ~DevPlan() { if (uploaded) (void)hipEventDestroy(uploaded); }
 };
-// a device buffer whose last use was ordered before `ready` on some stream
-struct RetiredBuf { void* buf; size_t cap; hipEvent_t ready; };
+// a device buffer whose last uses were ordered before `ready` (one event per stream that used it)
+struct RetiredBuf { void* buf; size_t cap; std::vector<hipEvent_t> ready; };
 // pinned host staging slot of the plan uploads: busy until `done`
 struct StageSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
 
@@ -269,6 +273,8 @@ struct PpgEngine {
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
+    unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
+    bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
     bool subtile = true;     // layer32 path, hidden 256: workgroups of two token blocks (three per 160-token tile) when whole tiles would leave two thirds of the CUs idle (PPGS_AMD_SUBTILE=0: whole tiles always)
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
@@ -304,6 +310,7 @@ struct PpgEngine {
 
     ~PpgEngine() {
         (void)hipSetDevice(device);
+        if (d_overflow) (void)hipFree(d_overflow);
         if (head_dbg) {
             unsigned long long h[64];
             (void)hipDeviceSynchronize();
@@ -377,7 +384,7 @@ struct PpgEngine {
             (void)hipFree(lin_dbg);
         }
         for (auto& kv : plans) if (kv.second->buf) (void)hipFree(kv.second->buf);
-        for (RetiredBuf& r : retired) { (void)hipFree(r.buf); (void)hipEventDestroy(r.ready); }
+        for (RetiredBuf& r : retired) { (void)hipFree(r.buf); for (hipEvent_t ev : r.ready) (void)hipEventDestroy(ev); }
         for (StageSlot& st : stage) { if (st.host) (void)hipHostFree(st.host); if (st.done) (void)hipEventDestroy(st.done); }
         for (hipStream_t st : side_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t ev : ev_join) (void)hipEventDestroy(ev);
@@ -408,6 +415,20 @@ int upload_f32(PpgEngine* e, const float* src, size_t n, size_t n_pad, float** d
 template <class F>
 int upload_matrix(PpgEngine* e, int rows, int cols, int rows_pad, int cols_pad, F get, char** dst) {
     const size_t n = (size_t)rows_pad * cols_pad;
+    if (e->split) {
+        // fp16x2: every 32 elements of a row as [32 hi halves | 32 lo halves] (PrecX2, ppg_device.h)
+        if (cols_pad % 32) return fail(PPG_EINVAL, "split-precision operand rows are multiples of 32 elements (%d)", cols_pad);
+        std::vector<uint16_t> tmp(2 * n, 0);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) {
+                const float v = get(r, c);
+                const uint16_t hi = host_f16(v);
+                const size_t at = ((size_t)r * cols_pad + (c / 32) * 32) * 2 + (c % 32);
+                tmp[at] = hi;
+                tmp[at + 32] = host_f16(v - host_f16_to_f32(hi));
+            }
+        return upload(e, tmp.data(), n * 4, reinterpret_cast<void**>(dst));
+    }
     if (e->sz == 2) {
         std::vector<uint16_t> tmp(n, 0);
         for (int r = 0; r < rows; ++r)
@@ -486,7 +507,7 @@ Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
     const size_t Ttile = layer32_tile_tokens(H);        // whole tiles of the layer32 kernel (X32 / AO32 layouts)
     const size_t Mt = (M + Ttile - 1) / Ttile * Ttile;
     w.x = take(Mt * H * 4);
-    w.xb = take(e->sz == 2 ? M * H * 2 : 0);
+    w.xb = take(e->sz == 2 ? M * H * 2 : (e->split ? M * H * 4 : 0));
     w.qk = take((size_t)w.qk_rows * 2 * H * e->sz);
     w.vt = take((size_t)H * w.vt_ld * e->sz);
     w.ao = take(Mt * H * e->sz);
@@ -535,6 +556,7 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
         DevPlan* hit = it->second.get();
         hit->stamp = ++e->plan_stamp;
         if (capturing) hit->pinned = true;
+        if (std::find(hit->users.begin(), hit->users.end(), stream) == hit->users.end()) hit->users.push_back(stream);
         // the tables went up asynchronously on the stream of the first use: another stream waits for them
         if (!hit->upload_done) {
             if (hipEventQuery(hit->uploaded) == hipSuccess) hit->upload_done = true;
@@ -574,18 +596,24 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
         memcpy(staging.data() + offs[gi].blk, grp.blk_win.data(), grp.blk_win.size() * sizeof(int));
         memcpy(staging.data() + offs[gi].item, grp.items.data(), grp.items.size() * sizeof(AttnItem));
     }
-    // bound the cache: evict the least recently used plan that no graph refers to; its buffer
-    // is retired behind an event on this stream (kernels already queued may still read it)
+    // bound the cache: evict the least recently used plan that no graph refers to; its buffer is retired behind
+    // one event per stream that ever used it (kernels queued on ANY of them may still read the tables)
     if (e->plans.size() >= 64) {
         auto victim = e->plans.end();
         for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt)
             if (!jt->second->pinned && (victim == e->plans.end() || jt->second->stamp < victim->second->stamp)) victim = jt;
         if (victim != e->plans.end()) {
             if (victim->second->buf) {
-                RetiredBuf r{victim->second->buf, victim->second->cap, nullptr};
-                HIP_OK(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
-                HIP_OK(hipEventRecord(r.ready, stream));
-                e->retired.push_back(r);
+                RetiredBuf r{victim->second->buf, victim->second->cap, {}};
+                std::vector<hipStream_t> streams = victim->second->users;
+                if (std::find(streams.begin(), streams.end(), stream) == streams.end()) streams.push_back(stream);
+                for (hipStream_t user : streams) {
+                    hipEvent_t ev = nullptr;
+                    HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    r.ready.push_back(ev);
+                    HIP_OK(hipEventRecord(ev, user));
+                }
+                e->retired.push_back(std::move(r));
             }
             e->plans.erase(victim);
         }
@@ -593,7 +621,9 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
     // a retired buffer that is large enough and no longer in use, else a new one
     for (size_t i = 0; i < e->retired.size(); ++i) {
         RetiredBuf& r = e->retired[i];
-        if (hipEventQuery(r.ready) != hipSuccess) continue;
+        bool idle = true;
+        for (hipEvent_t ev : r.ready) idle = idle && hipEventQuery(ev) == hipSuccess;
+        if (!idle) continue;
         if (r.cap >= total && dp->buf == nullptr) {
             dp->buf = r.buf; dp->cap = r.cap;
         } else if (e->retired.size() > 16) {
@@ -601,7 +631,7 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
         } else {
             continue;
         }
-        (void)hipEventDestroy(r.ready);
+        for (hipEvent_t ev : r.ready) (void)hipEventDestroy(ev);
         e->retired.erase(e->retired.begin() + i);
         --i;
     }
@@ -626,6 +656,7 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
     HIP_OK(hipEventCreateWithFlags(&dp->uploaded, hipEventDisableTiming));
     HIP_OK(hipEventRecord(dp->uploaded, stream));
     dp->upload_stream = stream;
+    dp->users.push_back(stream);
     for (size_t gi = 0; gi < p.groups.size(); ++gi) {
         char* base = static_cast<char*>(dp->buf);
         p.groups[gi].d_win = reinterpret_cast<PpgWindow*>(base + offs[gi].win);
@@ -842,8 +873,11 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (C < 1) return fail(PPG_EINVAL, "input_channels %d", C);
     if (cfg->chunk_length <= 2 * cfg->chunk_overlap || cfg->chunk_length > 512)
         return fail(PPG_EINVAL, "chunk_length %d / overlap %d unsupported", cfg->chunk_length, cfg->chunk_overlap);
-    if (cfg->precision != PPG_PRECISION_FP32 && cfg->precision != PPG_PRECISION_BF16 && cfg->precision != PPG_PRECISION_FP16)
+    if (cfg->precision != PPG_PRECISION_FP32 && cfg->precision != PPG_PRECISION_BF16 && cfg->precision != PPG_PRECISION_FP16 &&
+        cfg->precision != PPG_PRECISION_FP16X2)
         return fail(PPG_EINVAL, "precision %d", cfg->precision);
+    if (cfg->precision == PPG_PRECISION_FP16X2 && (H != 256 || dh != 128 || F % 64))
+        return fail(PPG_EINVAL, "the fp16x2 mode covers hidden 256 with head dimension 128 (hidden %d, head dimension %d)", H, dh);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(PPG_EDEVICE, "no HIP device: the PPG engine has no CPU path");
@@ -853,10 +887,11 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     std::unique_ptr<PpgEngine> e(new PpgEngine());
     e->cfg = *cfg;
     e->device = device;
-    e->sz = cfg->precision == PPG_PRECISION_FP32 ? 4 : 2;
+    e->split = cfg->precision == PPG_PRECISION_FP16X2;
+    e->sz = (cfg->precision == PPG_PRECISION_FP32 || e->split) ? 4 : 2;
     e->KG = 64 / e->sz;
     e->head_dim = dh;
-    e->Cp = round_up(C, e->KG);
+    e->Cp = round_up(C, e->split ? 32 : e->KG);      // (split operands: whole [32 hi | 32 lo] blocks)
     e->in_groups_per_tap = e->Cp / e->KG;
     e->in_total_groups = round_up(5 * e->in_groups_per_tap, 2);
     e->out_groups_per_tap = H / e->KG;
@@ -884,11 +919,17 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_SUBTILE")) e->subtile = atoi(v) != 0;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), 256));
+    HIP_OK(hipMemset(e->d_overflow, 0, 256));
     e->x16 = cfg->precision == PPG_PRECISION_BF16;
     if (const char* v = getenv("PPGS_AMD_X16")) e->x16 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_OUTCONV")) e->outconv = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) e->l32_debug = atoi(v);
     if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) e->h32_debug = atoi(v);
+    if (e->split) {
+        // the unfused launch sequence: Q/K/V, attention, out-projection + LayerNorm, FFN as one launch each
+        e->op_fused = false; e->qkv_fused = false; e->ffn_mixed = false; e->ffn_fused = true;
+    }
     if (!e->layer32 || H != 256 || e->Cp != 96 || !e->qkv_fused) e->head32 = false;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
@@ -975,13 +1016,13 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         if ((rc = plain(wts->linear1_weight[l], F, H, &d.w1))) return rc;
         if ((rc = paired(wts->linear2_weight[l], H, F, &d.w2))) return rc;
         d.wqkvk = d.wqkv;
-        if (e->sz == 4) {
+        if (e->sz == 4 && !e->split) {
             const float* w = in_w.data();
             rc = upload_matrix(E, 3 * H, H, 3 * H, H, [&](int r, int c) { return w[(size_t)pair_row(r) * H + pair_row(c)]; }, &d.wqkvk);
             if (rc) return rc;
         }
         d.w1k = d.w1;
-        if (e->sz == 4) {   // the fused prologue hands LN1's fp32 accumulators to phase A in paired K order
+        if (e->sz == 4 && !e->split) {   // the fused prologue hands LN1's fp32 accumulators to phase A in paired K order
             const float* w = wts->linear1_weight[l];
             rc = upload_matrix(E, F, H, F, H, [&](int r, int c) { return w[(size_t)r * H + pair_row(c)]; }, &d.w1k);
             if (rc) return rc;
@@ -991,7 +1032,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
             // hidden 16e + 4g + r (the two phase-A accumulators e of lane
             // group g, concatenated).  fp32: natural order.
             const float* w = wts->linear2_weight[l];
-            const bool bf = e->sz == 2;
+            const bool bf = e->sz == 2 || e->split;
             rc = upload_matrix(E, H, F, H, F,
                                [&](int row, int c) {
                                    const int r = pair_row(row);
@@ -1156,12 +1197,12 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     char* base = static_cast<char*>(workspace) + grp.ws_offset;
     char* xw = base + ws.xw;
     float* X = reinterpret_cast<float*>(base + ws.x);
-    char* Xb = e->sz == 2 ? base + ws.xb : nullptr;
+    char* Xb = (e->sz == 2 || e->split) ? base + ws.xb : nullptr;
     char* qk = base + ws.qk;
     char* vt = base + ws.vt;
     char* ao = base + ws.ao;
     char* hid = base + ws.hid;
-    const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
+    const char* act_x = (e->sz == 2 || e->split) ? Xb : reinterpret_cast<const char*>(X);
 
     const int nt = choose_nt(e, M, e->sz == 2 ? 3 : 2);     // linear / conv kernels
     // linear / conv kernels: measured best at C2 (two 256-register workgroups
@@ -1315,6 +1356,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.total_groups = e->out_total_groups;
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = out; a.out_T = frames; a.out_C = c.output_channels; a.softmax = softmax;
+        a.overflow = e->d_overflow;
         if (e->lin_dbg_class == PPG_K_OUTCONV_SOFTMAX) a.dbg = e->lin_dbg;
         if (e->outconv && ppg::outconv_supported(prec, a)) LAUNCH_OK(ppg::launch_outconv(prec, a, s), "out-conv+softmax");
         else LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, lnt_ln, a, 1, s), "out-conv+softmax");
@@ -1456,7 +1498,7 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     tb.win = off; off = align_up(off + 3 * (size_t)batch * sizeof(PpgWindow), 64);
     tb.meta = off; off = align_up(off + (size_t)batch * sizeof(StreamItemMeta), 64);
     tb.items = off; off = align_up(off + (size_t)tb.max_items * sizeof(AttnItem), 64);
-    tb.maps = off; off = align_up(off + 3 * (size_t)tb.max_blocks * sizeof(int), 64);
+    tb.maps = off; off = align_up(off + 3 * align_up((size_t)tb.max_blocks * sizeof(int), 64), 64) + 256;   // (packed per step, each map 64-byte aligned)
     tb.bytes = off;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_tables), tb.bytes));
     HIP_OK(hipMemset(st->d_tables, 0, tb.bytes));
@@ -1583,11 +1625,11 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
     const Workspace& ws = st->ws;
     char* xw = base + ws.xw;
     float* X = reinterpret_cast<float*>(base + ws.x);
-    char* Xb = e->sz == 2 ? base + ws.xb : nullptr;
+    char* Xb = (e->sz == 2 || e->split) ? base + ws.xb : nullptr;
     char* ao = base + ws.ao;
     auto qk_of = [&](int l) { return base + st->cache_off + (size_t)l * (st->qk_bytes + st->vt_bytes); };
     auto vt_of = [&](int l) { return qk_of(l) + st->qk_bytes; };
-    const char* act_x = e->sz == 2 ? Xb : reinterpret_cast<const char*>(X);
+    const char* act_x = (e->sz == 2 || e->split) ? Xb : reinterpret_cast<const char*>(X);
 
     if (nmap[2] > 0) {
         GatherArgs g{};
@@ -1668,6 +1710,7 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
         a.total_groups = e->out_total_groups;
         a.W = e->w_out; a.bias = e->b_out; a.N = 48;
         a.out = st->probs; a.out_T = R; a.out_C = c.output_channels; a.softmax = softmax;
+        a.overflow = e->d_overflow;
         a.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[1]); a.map_blocks = nmap[1];
         LAUNCH_OK(ppg::launch_linear(prec, EPI_OUTCONV, 3, 1, a, 1, s), "stream out-conv+softmax");
     }
@@ -2169,6 +2212,18 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
         }
     }
     if (he != hipSuccess) return fail(PPG_EDEVICE, "frontend: %s", hipGetErrorString(he));
+    return PPG_OK;
+}
+
+int ppg_engine_nonfinite(PpgEngine* e, int clear, int* flag) {
+    if (!e || !flag) return fail(PPG_EINVAL, "null argument");
+    if (!e->d_overflow) { *flag = 0; return PPG_OK; }
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_OK(hipSetDevice(e->device));
+    unsigned value = 0;
+    HIP_OK(hipMemcpy(&value, e->d_overflow, sizeof(value), hipMemcpyDeviceToHost));      // (synchronises with the device)
+    if (value && clear) HIP_OK(hipMemset(e->d_overflow, 0, sizeof(value)));
+    *flag = (int)value;
     return PPG_OK;
 }
 

@@ -147,8 +147,8 @@ __device__ __forceinline__ void resln(
             if constexpr (MODE != LN_KEEP) {
                 if (ok[t]) {
                     *reinterpret_cast<float4*>(xrow[t] + n) = make_float4(y0, y1, y2, y3);
-                    if constexpr (P::kIsBF16 && MODE != LN_NO_RESIDUAL_KEEP)
-                        pair[t].put(Xb + ((size_t)(tok0 + 16 * t + idx) * H + (n & ~7)) * 2, nb & 1, y0, y1, y2, y3);
+                    if constexpr ((P::kIsBF16 || P::kSplit) && MODE != LN_NO_RESIDUAL_KEEP)
+                        pair[t].put(Xb + (size_t)(tok0 + 16 * t + idx) * H * P::kBytes + P::row_byte(n & ~7), nb & 1, y0, y1, y2, y3);
                 }
             }
         }
@@ -336,8 +336,16 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
             const int m = row_of(tl);
             if (m < a.M && c0 + c < a.Cp) {
                 const float v = tile[c][tl];
-                typename P::elem* dst = reinterpret_cast<typename P::elem*>(a.xw) + (size_t)m * a.Cp + c0 + c;
-                *dst = P::cvt1(v);
+                if constexpr (P::kSplit) {
+                    char* row = a.xw + (size_t)m * a.Cp * P::kBytes + P::row_byte(c0 + c);
+                    uint32_t hi, lo;
+                    P::split2(v, 0.f, hi, lo);
+                    *reinterpret_cast<uint16_t*>(row) = (uint16_t)hi;
+                    *reinterpret_cast<uint16_t*>(row + 64) = (uint16_t)lo;
+                } else {
+                    typename P::elem* dst = reinterpret_cast<typename P::elem*>(a.xw) + (size_t)m * a.Cp + c0 + c;
+                    *dst = P::cvt1(v);
+                }
             }
         }
     }
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 vcol[t] = -1;
                 if (vw[t] >= 0) {
                     const int ttb = mb - a.win[vw[t]].tok_off;   // multiple of 16
-                    if constexpr (P::kIsBF16) vcol[t] = a.win[vw[t]].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
+                    if constexpr (P::kIsBF16 || P::kSplit) vcol[t] = a.win[vw[t]].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
                     else vcol[t] = a.win[vw[t]].vt_off + ttb;
                 }
             }
@@ -484,8 +492,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                     constexpr int i = decltype(ic)::value;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        if constexpr (SWAP) P::mma(acc[i % NB][t], acur[i / NB][t], wf);
-                        else P::mma(acc[i % NB][t], wf, acur[i / NB][t]);
+                        mma_kg<P, i / NB, SWAP, 0>(acc[i % NB][t], wf, acur, t, acc[i % NB][t]);
                     }
                 });
             if (more) {
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.X) + x16_index(m, n, a.H)) = make_uint2(pack_f16x2(y.x, y.y), pack_f16x2(y.z, y.w));
                     else
                         *reinterpret_cast<float4*>(a.X + (a.x_tiled ? x32_index(m, n, a.H) : (size_t)m * a.H + n)) = y;
-                    if constexpr (P::kIsBF16) pair[t].put(a.Xb + ((size_t)m * a.H + (n & ~7)) * 2, nb & 1, y.x, y.y, y.z, y.w);
+                    if constexpr (P::kIsBF16 || P::kSplit) pair[t].put(a.Xb + (size_t)m * a.H * P::kBytes + P::row_byte(n & ~7), nb & 1, y.x, y.y, y.z, y.w);
                 }
             }
         }
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 for (int t = 0; t < NT; ++t) {
                     const int m = tok0 + 16 * t + idx;
                     if (m >= a.M) continue;
-                    pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
+                    pair[t].put(a.out_rows + (size_t)m * a.out_ld * P::kBytes + P::row_byte(n & ~7), nb & 1,
                                 acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y,
                                 acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w);
                 }
@@ -581,12 +588,24 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 if (vw[t] < 0) continue;
                 constexpr int kLast = NT - 1;
                 const int tn = t < kLast ? t + 1 : t;
-                const bool paired = P::kIsBF16 && t < kLast && vw[tn] == vw[t] && (vcol[t] & 4) == 0;
+                const bool paired = (P::kIsBF16 || P::kSplit) && t < kLast && vw[tn] == vw[t] && (vcol[t] & 4) == 0;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int row = n0 + nb * 16 + idx;                       // tile row
                     const float bv = a.bias[n0 + pair_row(nb * 16 + idx)];
-                    char* dst = a.vt + ((size_t)(row - a.v_start) * a.vt_ld + vcol[t] + (P::kIsBF16 ? 8 : 4) * g) * P::kBytes;
+                    char* dst = a.vt + (size_t)(row - a.v_start) * a.vt_ld * P::kBytes + P::row_byte(vcol[t] + ((P::kIsBF16 || P::kSplit) ? 8 : 4) * g);
+                    if constexpr (P::kSplit) {
+                        if (paired) {          // both planes of the 8 columns of the (even, odd) block pair
+                            uint32_t h[4], l[4];
+                            P::split2(acc[nb][t][0] + bv, acc[nb][t][1] + bv, h[0], l[0]);
+                            P::split2(acc[nb][t][2] + bv, acc[nb][t][3] + bv, h[1], l[1]);
+                            P::split2(acc[nb][tn][0] + bv, acc[nb][tn][1] + bv, h[2], l[2]);
+                            P::split2(acc[nb][tn][2] + bv, acc[nb][tn][3] + bv, h[3], l[3]);
+                            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+                            *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+                            continue;
+                        }
+                    }
                     if (paired) {
                         *reinterpret_cast<u32x4*>(dst) = u32x4{
                             P::pack2(acc[nb][t][0] + bv, acc[nb][t][1] + bv), P::pack2(acc[nb][t][2] + bv, acc[nb][t][3] + bv),
@@ -670,7 +689,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             const bool live = tm[t].w >= 0 && tm[t].tt < tm[t].frames;
             const bool valid = live && tm[t].tt < tm[t].valid;
             float v[NB][4];
-            float mx = -INFINITY;
+            float mx = -INFINITY, chk = 0.f;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const float4 bv = *reinterpret_cast<const float4*>(a.bias + nb * 16 + 4 * g);
@@ -680,8 +699,10 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                     const int n = nb * 16 + 4 * g + r;
                     v[nb][r] = valid ? acc[nb][t][r] + bb[r] : 0.f;
                     if (n < a.out_C) mx = fmaxf(mx, v[nb][r]);
+                    if (n < a.out_C) chk = fmaf(v[nb][r], 0.f, chk);     // NaN as soon as one logit is NaN or infinite
                 }
             }
+            if (chk != chk && a.overflow) atomicOr(a.overflow, 1u);
             if (a.softmax) {
                 mx = wave_max_g(mx);
                 float sum = 0.f;
@@ -824,7 +845,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
 
     // B fragments of the wave's tokens: x (bf16 copy / fp32 X), or with OP the
     // attention output, replaced by LN1's result below
-    const char* actp = OP ? a.ao : (P::kIsBF16 ? a.Xb : reinterpret_cast<const char*>(a.X));
+    const char* actp = OP ? a.ao : ((P::kIsBF16 || P::kSplit) ? a.Xb : reinterpret_cast<const char*>(a.X));
     u32x4 xf[XG][NTX];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -867,7 +888,16 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         constexpr int u = decltype(uc)::value;
         constexpr int hb = u / NTB, t = u % NTB;
         const f32x4 hv = [&] { if constexpr (t < NTL) return hsrc[hb][t]; else return hfar[hb]; }();
-        if constexpr (P::kIsBF16) {
+        if constexpr (P::kSplit) {
+            // (a chunk is ONE 32-wide hidden group: blocks 0, 1 are the two halves of the lane's 8 k-slots; hf[0] the hi
+            // plane, hf[1] the lo plane -- the 16-bit path's slot order, so W2 is packed as for the 16-bit modes)
+            static_assert(HB == 2 && HG == 2, "split operands: hidden 256 (one 32-wide hidden group per chunk)");
+            uint32_t h01, l01, h23, l23;
+            P::split2(fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), h01, l01);
+            P::split2(fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f), h23, l23);
+            if constexpr (hb & 1) { hf[0][t].z = h01; hf[0][t].w = h23; hf[1][t].z = l01; hf[1][t].w = l23; }
+            else                  { hf[0][t].x = h01; hf[0][t].y = h23; hf[1][t].x = l01; hf[1][t].y = l23; }
+        } else if constexpr (P::kIsBF16) {
             const uint32_t lo = P::relu2(P::pack2(hv[0], hv[1])), hi = P::relu2(P::pack2(hv[2], hv[3]));
             if constexpr (hb & 1) { hf[hb >> 1][t].z = lo; hf[hb >> 1][t].w = hi; }
             else                  { hf[hb >> 1][t].x = lo; hf[hb >> 1][t].y = hi; }
@@ -891,9 +921,9 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
 #pragma unroll
             for (int t = 0; t < COUNT; ++t) {
                 if constexpr (i / HB == 0) {
-                    if constexpr (std::is_same_v<decltype(cinit), std::nullptr_t>) P::mma0(dst[OFF + i % HB][t], wf, xf[0][t]);
-                    else P::mmac(dst[OFF + i % HB][t], wf, xf[0][t], cinit[i % HB]);
-                } else P::mma(dst[OFF + i % HB][t], wf, xf[i / HB][t]);
+                    if constexpr (std::is_same_v<decltype(cinit), std::nullptr_t>) mma_kg<P, 0, false, 1>(dst[OFF + i % HB][t], wf, xf, t, dst[OFF + i % HB][t]);
+                    else mma_kg<P, 0, false, 2>(dst[OFF + i % HB][t], wf, xf, t, cinit[i % HB]);
+                } else mma_kg<P, i / HB, false, 0>(dst[OFF + i % HB][t], wf, xf, t, dst[OFF + i % HB][t]);
             }
             filler(ic);
         });
@@ -1016,7 +1046,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
         lds_stream<LB, HG * NBH, DEPTH>(fbb, [&](auto ic, const u32x4& wf) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) P::mma(yacc[i % NBH][t], wf, hf[i / NBH][t]);
+            for (int t = 0; t < NT; ++t) mma_kg<P, i / NBH, false, 0>(yacc[i % NBH][t], wf, hf, t, yacc[i % NBH][t]);
         });
         stamp(c, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1301,7 +1331,7 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
         const float y2 = (v[h].z - mean) * rstd * gv.z + ev.z;
         const float y3 = (v[h].w - mean) * rstd * gv.w + ev.w;
         *reinterpret_cast<float4*>(a.X + (size_t)m * H + n) = make_float4(y0, y1, y2, y3);
-        if constexpr (P::kIsBF16) store4<P>(a.Xb + ((size_t)m * H + n) * 2, y0, y1, y2, y3);
+        if constexpr (P::kIsBF16 || P::kSplit) store4<P>(a.Xb + (size_t)m * H * P::kBytes + P::row_byte(n), y0, y1, y2, y3);
     }
 }
 
@@ -1398,8 +1428,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int t = 0; t < NTQ; ++t) {
-                if constexpr (i / KB == 0) P::mmac(s[i % KB][t], kf, qf[0][t], cinit[t]);
-                else P::mma(s[i % KB][t], kf, qf[i / KB][t]);
+                mma_kg<P, i / KB, false, (i / KB == 0 ? 2 : 0)>(s[i % KB][t], kf, qf, t, cinit[t]);
             }
             filler(ic);
         });
@@ -1440,7 +1469,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         const float p2 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][2] - d : s[kb][t][2]);
         const float p3 = __builtin_amdgcn_exp2f(MOVED ? s[kb][t][3] - d : s[kb][t][3]);
         psum[t] += (p0 + p1) + (p2 + p3);
-        if constexpr (P::kIsBF16) {
+        if constexpr (P::kSplit) {
+            // (a tile is ONE 32-key group: pf[0] the hi plane of its 8 k-slots per lane, pf[1] the lo plane)
+            uint32_t h01, l01, h23, l23;
+            P::split2(p0, p1, h01, l01);
+            P::split2(p2, p3, h23, l23);
+            if (kb & 1) { pf[0][t].z = h01; pf[0][t].w = h23; pf[1][t].z = l01; pf[1][t].w = l23; }
+            else        { pf[0][t].x = h01; pf[0][t].y = h23; pf[1][t].x = l01; pf[1][t].y = l23; }
+        } else if constexpr (P::kIsBF16) {
             const uint32_t lo = P::pack2(p0, p1), hi = P::pack2(p2, p3);
             if (kb & 1) { pf[kb >> 1][t].z = lo; pf[kb >> 1][t].w = hi; }
             else        { pf[kb >> 1][t].x = lo; pf[kb >> 1][t].y = hi; }
@@ -1557,7 +1593,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             [&](auto ic, const u32x4& vf) {
                 constexpr int i = decltype(ic)::value;
 #pragma unroll
-                for (int t = 0; t < NTQ; ++t) P::mma(oacc[i % DB][t], vf, pf[i / DB][t]);
+                for (int t = 0; t < NTQ; ++t) mma_kg<P, i / DB, false, 0>(oacc[i % DB][t], vf, pf, t, oacc[i % DB][t]);
             });
         stamp(kt, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1581,7 +1617,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const int n = head * DH + pair_feature(db, g);
-            pair.put(a.ao + ((a.ao_tiled && P::kIsBF16) ? ao32_byte(m, n & ~7, a.H) : ((size_t)m * a.H + (n & ~7)) * P::kBytes), db & 1,
+            pair.put(a.ao + ((a.ao_tiled && P::kIsBF16) ? ao32_byte(m, n & ~7, a.H) : (size_t)m * a.H * P::kBytes + P::row_byte(n & ~7)), db & 1,
                      oacc[db][t][0] * inv, oacc[db][t][1] * inv,
                      oacc[db][t][2] * inv, oacc[db][t][3] * inv);
         }
@@ -1735,6 +1771,25 @@ hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim,
     return hipGetLastError();
 }
 
+// Split-precision operands (PrecX2): the token-split kernels of the unfused launch sequence at hidden 256
+template <int NT>
+hipError_t launch_linear_x2_nt(int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s) {
+    switch (epi) {
+    case EPI_INCONV:  return launch_linear_t<PrecX2, NT, 16, EPI_INCONV>(a, ypasses, s);
+    case EPI_QKV:     return launch_linear_t<PrecX2, NT, 16, EPI_QKV>(a, ypasses, s);
+    case EPI_OUTCONV: return launch_linear_t<PrecX2, NT, 3, EPI_OUTCONV>(a, ypasses, s);
+    case EPI_RESLN:   return nb == 16 ? launch_linear_t<PrecX2, 1, 16, EPI_RESLN>(a, ypasses, s) : hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_linear_x2(int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s) {
+    return nt == 1 ? launch_linear_x2_nt<1>(epi, nb, a, ypasses, s) : launch_linear_x2_nt<2>(epi, nb, a, ypasses, s);
+}
+hipError_t launch_ffn_x2(const FfnArgs& a, int nt, hipStream_t s) {
+    if (a.H != 256 || a.Wo != nullptr || a.Wq != nullptr) return hipErrorInvalidValue;
+    return nt == 1 ? launch_ffn_t<PrecX2, 1, 16, false, false>(a, s) : launch_ffn_t<PrecX2, 2, 16, false, false>(a, s);
+}
+
 }  // namespace
 
 namespace ppg {
@@ -1747,10 +1802,19 @@ int attn_query_tile(int head_dim) { return head_dim == 128 ? 128 : 64; }   // (d
 #else
 #define PPG_OTHER_PRECISIONS 1
 #endif
+// (-DPPG_ONLY_BF16 -DPPG_WITH_X2: bf16 and the split-precision mode)
+#if PPG_OTHER_PRECISIONS || defined(PPG_WITH_X2)
+#define PPG_X2 1
+#else
+#define PPG_X2 0
+#endif
 
 hipError_t launch_gather(int precision, const GatherArgs& a, hipStream_t s) {
     dim3 grid(a.rowmap ? (a.map_blocks + 3) / 4 : (a.M + 63) / 64, (a.Cp + 31) / 32 + 1);       // + the housekeeping row
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(gather_kernel<PrecBF16>, grid, dim3(256), 0, s, a);
+#if PPG_X2
+    else if (precision == PPG_PRECISION_FP16X2) hipLaunchKernelGGL(gather_kernel<PrecX2>, grid, dim3(256), 0, s, a);
+#endif
 #if PPG_OTHER_PRECISIONS
     else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(gather_kernel<PrecF16>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gather_kernel<PrecF32>, grid, dim3(256), 0, s, a);
@@ -1768,6 +1832,9 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
 
 hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArgs& a, int ypasses, hipStream_t s) {
     if (precision == PPG_PRECISION_BF16) return launch_linear_p<PrecBF16>(epi, nb, nt, a, ypasses, s);
+#if PPG_X2
+    if (precision == PPG_PRECISION_FP16X2) return launch_linear_x2(epi, nb, nt, a, ypasses, s);
+#endif
 #if PPG_OTHER_PRECISIONS
     if (precision == PPG_PRECISION_FP16) return launch_linear_p<PrecF16>(epi, nb, nt, a, ypasses, s);
     return launch_linear_p<PrecF32>(epi, nb, nt, a, ypasses, s);
@@ -1778,6 +1845,9 @@ hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArg
 
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s) {
     if (precision == PPG_PRECISION_BF16) return launch_ffn_p<PrecBF16>(a, nt, s);
+#if PPG_X2
+    if (precision == PPG_PRECISION_FP16X2) return launch_ffn_x2(a, nt, s);
+#endif
 #if PPG_OTHER_PRECISIONS
     if (precision == PPG_PRECISION_FP16) return launch_ffn_p<PrecF16>(a, nt, s);
     return launch_ffn_p<PrecF32>(a, nt, s);
@@ -1793,6 +1863,13 @@ hipError_t launch_attn(int precision, const AttnArgs& args, int nitems, int head
     const char* mode = getenv("PPGS_AMD_ATTN_REBASE");
     a.rebase_always = (mode && strcmp(mode, "always") == 0) ? 1 : 0;
     if (precision == PPG_PRECISION_BF16) return launch_attn_p<PrecBF16>(a, nitems, heads, head_dim, s);
+#if PPG_X2
+    if (precision == PPG_PRECISION_FP16X2) {
+        if (head_dim != 128) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(attn_mixed_kernel<PrecX2>, dim3(nitems * heads), dim3(256), 65536, s, a);
+        return hipGetLastError();
+    }
+#endif
 #if PPG_OTHER_PRECISIONS
     if (precision == PPG_PRECISION_FP16) return launch_attn_p<PrecF16>(a, nitems, heads, head_dim, s);
     return launch_attn_p<PrecF32>(a, nitems, heads, head_dim, s);

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void outconv_kernel(LinearArgs a) {
         const bool live = tm.w >= 0 && tm.tt < tm.frames;
         const bool valid = live && tm.tt < tm.valid;
         float v[NB][4];
-        float mx = -INFINITY;
+        float mx = -INFINITY, chk = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void outconv_kernel(LinearArgs a) {
                 const int n = nb * 16 + 4 * g + r;
                 v[nb][r] = valid ? acc[nb][r] + bias[nb][r] : 0.f;
                 if (n < a.out_C) mx = fmaxf(mx, v[nb][r]);
+                if (n < a.out_C) chk = fmaf(v[nb][r], 0.f, chk);         // NaN as soon as one logit is NaN or infinite
             }
+        if (chk != chk && a.overflow) atomicOr(a.overflow, 1u);          // the engine's sticky flag (see LinearArgs)
         if (a.softmax) {
             mx = wave_max_g(mx);
             float sum = 0.f;

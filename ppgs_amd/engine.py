@@ -14,7 +14,7 @@ import torch
 from . import config, weights
 
 PPG_MAX_LAYERS = 16
-PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2}
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'fp16': 2, 'fp16x2': 3}
 KERNEL_CLASSES = (
     'gather', 'inconv', 'qkv', 'attention', 'outproj_ln', 'ffn',
     'outconv_softmax', 'frontend')
@@ -141,6 +141,7 @@ SYMBOLS = {
     'ppg_stream_push': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    'ppg_engine_nonfinite': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'ppg_stream_create_batch': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'ppg_stream_batch': (ctypes.c_int, [ctypes.c_void_p]),
@@ -329,6 +330,23 @@ class Engine:
         """A KV-cached causal stream over one utterance of up to `max_frames` frames
         (see Stream); the engine must be causal."""
         return Stream(self, max_frames, dtype)
+
+    def nonfinite(self, clear=True):
+        """True when a launch of this engine produced a non-finite logit for a valid frame since the
+        flag was last cleared (synchronises with the device): fp16 operands past 65504, or
+        non-finite input features."""
+        flag = ctypes.c_int()
+        with torch.cuda.device(self.device):
+            _check(self._lib.ppg_engine_nonfinite(self._handle, int(clear), ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def check_finite(self):
+        """Raise PpgError if nonfinite() (and clear the flag)."""
+        if self.nonfinite(clear=True):
+            raise PpgError(
+                f'ppgs_amd: non-finite logits ({self.precision} operands): an activation left the operand '
+                "format's range (fp16: |x| < 65504) or the input features are not finite; "
+                'PPGS_AMD_PRECISION=bf16 or fp32 has the range of fp32')
 
     def batched_stream(self, batch, max_frames, dtype=torch.float16):
         """KV-cached causal streams over `batch` utterances advanced together (see

@@ -1242,3 +1242,79 @@ def test_batched_kv_cached_streams_equal_causal_forward(precision):
         assert np.abs(got - ref[b]).max() < tol, b
     with pytest.raises(ValueError):
         stream.push(torch.zeros(batch, 80, 4).cuda(), [4] * batch)        # every item was flushed
+
+
+def test_fp16_overflow_sets_the_sticky_flag():
+    """fp16 operands end at 65504.  A checkpoint whose FFN activations pass that (layer 2's linear1 scaled by 3e4)
+    turns into NaN posteriors in the fp16 mode: the engine's sticky flag reports it (Engine.nonfinite /
+    check_finite, which the file pipelines consult before saving), the bf16 mode (fp32's exponent range) stays
+    finite on the same weights, and an ordinary checkpoint never sets the flag."""
+    gen = torch.Generator().manual_seed(8)
+    feats = torch.randn(2, 80, 120, generator=gen).half().cuda()
+    engine, _ = eng(precision='fp16')
+    engine.encode(feats, [120, 77])
+    assert engine.nonfinite() is False
+    state = W.seeded_state_dict(seed=1234)
+    state = {k: v.clone() for k, v in state.items()}
+    state['model.layers.2.linear1.weight'] *= 3e4
+    wild = E.Engine(state, 0, 'fp16')
+    out = wild.encode(feats, [120, 77])
+    assert not bool(torch.isfinite(out[0]).all())
+    assert wild.nonfinite(clear=False) is True
+    with pytest.raises(E.PpgError):
+        wild.check_finite()
+    assert wild.nonfinite() is False                       # cleared by check_finite
+    wide = E.Engine(state, 0, 'bf16')
+    out = wide.encode(feats, [120, 77])
+    assert bool(torch.isfinite(out).all()) and wide.nonfinite() is False
+
+
+def test_fp16x2_mode_meets_the_fp32_bar(golden):
+    """The compensated 16-bit mode (PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes, three fp16 MFMAs per
+    product, fp32 accumulation): posteriors within 1e-4 -- the bar of the fp32 mode -- of the reference fixtures on
+    the seeded AND the sharpened checkpoint (where plain fp16 operands are 3e-3 off), single window, chunked,
+    causal, through the reference's own glue (g7_glue, fp32 route), on ragged batches against the oracle, and at
+    the benchmark size (statistics fixture G6 and spot utterances)."""
+    engine, state = eng(precision='fp16x2')
+    sharp, _ = eng(seed=4321, sharpen=2.0, precision='fp16x2')
+    g = golden('g2_single_window')
+    ppg = run(engine, g['features'], g['lengths'])
+    assert np.abs(ppg - g['ppg']).max() < FP32_TOL
+    assert np.allclose(ppg.sum(1), 1, atol=1e-5)
+    ppg = run(sharp, g['features'], g['lengths'])
+    assert np.abs(ppg - g['ppg_sharp']).max() < FP32_TOL
+    g3 = golden('g3_chunked')
+    for tag in 'abc':
+        ppg = run(engine, g3[f'features_{tag}'], g3[f'lengths_{tag}'])
+        assert np.abs(ppg - g3[f'ppg_{tag}']).max() < FP32_TOL, tag
+    ppg = run(sharp, g3['features_a'], g3['lengths_a'])
+    assert np.abs(ppg - g3['ppg_a_sharp']).max() < FP32_TOL
+    causal, _ = eng(precision='fp16x2', causal=True)
+    ppg = run(causal, g['features'], g['lengths'])
+    assert np.abs(ppg - g['ppg_causal']).max() < FP32_TOL
+    g7 = golden('g7_glue')
+    mel = ppgs_amd.preprocess.mel.from_audios(t(g7['audio']).cuda())
+    for model, tag in ((engine, ''), (sharp, '_sharp')):
+        ppg = model.encode(mel, [100]).cpu().numpy()
+        assert np.abs(ppg - g7[f'ppg_fp32{tag}']).max() < FP32_TOL, tag
+    ppg = run(engine, g7['batch_features'], g7['batch_lengths'])
+    assert np.abs(ppg - g7['batch_ppg_fp32']).max() < FP32_TOL
+    # ragged batches (0-length items, lengths around the chunk rule's edges) against the oracle
+    gen = torch.Generator().manual_seed(17)
+    for T, lengths in ((501, [501, 0, 33]), (850, [850, 400, 17, 849]), (64, [64, 1])):
+        feats = torch.randn(len(lengths), 80, T, generator=gen).half()
+        ref = O.from_features(state, feats.float(), torch.tensor(lengths)).numpy()
+        out = run(engine, feats.numpy(), lengths)
+        assert np.abs(out - ref).max() < FP32_TOL, (T, lengths)
+    # the benchmark size: statistics of the reference (G6) and the small-batch path (hidden splits)
+    g6 = golden('g6_c2_stats')
+    agen = torch.Generator().manual_seed(1234)
+    audio = (0.1 * torch.randn(32, 1, 160000, generator=agen)).cuda()
+    mel = ppgs_amd.preprocess.mel.from_audios(audio)
+    ppg = engine.encode(mel, [1000] * 32).cpu()
+    assert bool(torch.isfinite(ppg).all())
+    assert np.abs(ppg[0, :, :64].numpy() - g6['ppg_item0_first64']).max() < FP32_TOL
+    assert np.abs(ppg[31, :, -64:].numpy() - g6['ppg_item31_last64']).max() < FP32_TOL
+    assert np.abs(ppg.mean(-1).numpy() - g6['ppg_mean']).max() < FP32_TOL
+    with pytest.raises((ValueError, E.PpgError)):
+        E.Engine(W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512), 0, 'fp16x2')
