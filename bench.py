@@ -163,7 +163,7 @@ def pmc_traffic(kernel):
     lines = [line for line in open(files[-1]) if line.startswith(kernel)]
     # several variants of the kernel in one run: the one with the Q/K/V tail
     # (4 of the 5 launches of a step) is the one the roofline line describes
-    tail = [line for line in lines if 'true>' in line.split(':')[0] or 'Lb1' in line.split(':')[0]]
+    tail = [line for line in lines if re.search(r', true\b|Lb1', line.split(':')[0])]
     for line in tail or lines:
         m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
         fetch = float(m.group(1)) if m else fetch

@@ -266,6 +266,7 @@ struct PpgEngine {
     bool ffn_fused = true;
     bool qkv_fused = true;   // next layer's Q/K/V projection as the tail of the fused FFN kernel (PPGS_AMD_QKV_FUSED=0: own kernel)
     int ffn_split_max = 0;   // PPGS_AMD_FFN_SPLIT_MAX: cap on the hidden splits (0: half the chunks)
+    int ffn_splits_forced = 0;   // PPGS_AMD_FFN_SPLITS: this many hidden splits whatever the tile count (experiments)
     bool ffn_mixed = true;   // allow the mixed 3/3/2/2-block tiling of the fused layer kernel (PPGS_AMD_FFN_MIXED=0 disables)
     bool op_fused = true;    // attention out-projection + LN1 inside the FFN kernel (PPGS_AMD_OP_FUSED=0: own kernel)
     bool attn_xcd = true;    // attention items interleaved so that the query tiles of one (window, head) share an XCD's L2 (PPGS_AMD_ATTN_XCD=0: plain longest-first order)
@@ -481,6 +482,18 @@ void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) 
             while (splits * 2 <= cap && tiles_max_nt * splits * 2 <= e->num_cus) splits *= 2;
         }
     }
+    // 4-byte operand modes (fp32, fp16x2) cannot hold more than 128 tokens in LDS, so a launch whose tiles
+    // need a fraction over a whole number of rounds of the chip (C2: 320 tiles on 256 CUs = 2 rounds, the
+    // second a quarter full) is cut into hidden splits instead: ceil(tiles * s / CUs) / s rounds of full tiles
+    if (splits == 1 && e->sz == 4 && e->ffn_split && e->ffn_fused && e->ffn_nt == 0 && !e->op_fused) {
+        const int tiles = (M + 64 * max_nt - 1) / (64 * max_nt);
+        auto rounds = [&](int sp) { return (double)((tiles * sp + e->num_cus - 1) / e->num_cus) / sp + 0.08 * (sp > 1 ? 1 + 0.5 * sp : 0); };
+        int best = 1;
+        for (int sp = 2; sp <= 4 && sp <= chunks / 2; sp *= 2)
+            if (rounds(sp) < rounds(best)) best = sp;
+        if (best > 1) { nt = max_nt; splits = best; }
+    }
+    if (e->ffn_splits_forced > 0 && e->ffn_fused) { nt = max_nt; splits = e->ffn_splits_forced; }
     // mixed tiling (160-token workgroups, ppg_kernels.hip ffn_mixed_kernel): 2.5 blocks of
     // MFMA work per wave and chunk instead of nt; worth it when it saves a round or
     // shortens the one round there is (C2: 256 workgroups on 256 CUs instead of 214 larger ones)
@@ -913,6 +926,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_OP_FUSED")) e->op_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_FFN_MIXED")) e->ffn_mixed = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_FFN_SPLIT_MAX")) e->ffn_split_max = atoi(v);
+    if (const char* v = getenv("PPGS_AMD_FFN_SPLITS")) e->ffn_splits_forced = atoi(v);
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
