@@ -35,6 +35,11 @@ with ``--warmup 5`` times that ramp.
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the
 layer kernel): algorithmic FLOPs per launch / its mean launch duration
 measured with HIP events on the launch stream inside the timed region.
+The engine runs a batch of this size as TWO pipelines (half-batches on two HIP
+streams, bit-identical to one): a layer launch is then 128 one-per-CU workgroups,
+its ceiling is the MFMA peak of the 128 CUs it can occupy (`roofline.peak`,
+`peak_scope`; `frac_of_whole_chip` beside it), and `alt_single_pipeline` is the
+same step with PPGS_AMD_STREAMS=1, where a launch has the whole chip.
 `cpu_baseline` is the CPU oracle (fp32 restatement of the reference path,
 proven equal to the reference modules by tests/test_oracle_golden.py) timed on
 the host cores on the same 32 x 1000 batch, plus its bf16-autocast variant
@@ -318,11 +323,13 @@ def run_c2(args, rank, world, local_rank, use_dist):
                   'max_abs_vs_fp16': float((x2_out - alt_out).abs().max())}
         del other
     alt_streams = None
-    if rank == 0 and world == 1 and not args.no_alt and 'PPGS_AMD_STREAMS' not in os.environ:
-        # the same step with the batch split into two half-batches on two HIP streams of one engine: one half's
-        # memory-bound phases run beside the other half's MFMA phases.  Not the default configuration: kernels of the
-        # two halves overlap, so no per-kernel duration (no roofline fraction) can be read off such a run.
-        os.environ['PPGS_AMD_STREAMS'] = '2'
+    _, info = E.plan_windows(BATCH, FRAMES, lengths)
+    pipelines = model.pipelines(info.tokens)
+    if rank == 0 and world == 1 and not args.no_alt and 'PPGS_AMD_STREAMS' not in os.environ and pipelines > 1:
+        # the same step as ONE pipeline (PPGS_AMD_STREAMS=1): every launch then has the whole chip to itself, which is
+        # the configuration a per-kernel whole-chip roofline fraction can be read from; it is the slower one (the
+        # half-batches' memory-bound phases no longer run beside each other's MFMA phases), so it is not the default.
+        os.environ['PPGS_AMD_STREAMS'] = '1'
         try:
             other = E.Engine(state, local_rank, args.precision)
         finally:
@@ -330,23 +337,33 @@ def run_c2(args, rank, world, local_rank, use_dist):
         for _ in range(max(args.warmup, 3)):
             step(other)
         prewarm(other)
-        s2_elapsed, s2_out = timed_block(other)
-        alt_streams = {'streams': 2, 'ms_per_step': 1e3 * s2_elapsed / args.steps,
-                       'value': BATCH * FRAMES * args.steps / s2_elapsed,
-                       'max_abs_vs_one_stream': float((s2_out - out).abs().max())}
+        other.profile(True, classes=['ffn'], stride=EVENT_STRIDE)
+        s1_elapsed, s1_out = timed_block(other)
+        s1_ms, s1_samples = other.profile_read()['ffn']
+        other.profile(False)
+        alt_streams = {'pipelines': 1, 'ms_per_step': 1e3 * s1_elapsed / args.steps,
+                       'value': BATCH * FRAMES * args.steps / s1_elapsed,
+                       'mean_launch_ms': s1_ms / max(s1_samples, 1), 'timed_launches': s1_samples,
+                       'max_abs_vs_default': float((s1_out - out).abs().max())}
         del other
 
     if rank != 0:
         return None
     ms_per_step = 1e3 * elapsed / args.steps
     frames_per_s = world * BATCH * FRAMES * args.steps / elapsed
-    _, info = E.plan_windows(BATCH, FRAMES, lengths)
     launches_per_layer = max(kernels['ffn'][1] // (LAYERS * breakdown_steps), 1)
     flops_per_frame, op_fused, qkv_fused_layers = layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer)
     ffn_flops = flops_per_frame * info.processed_frames / launches_per_layer
     ffn_tflops = ffn_flops / (1e-3 * ffn_ms / max(ffn_samples, 1)) / 1e12
     peak = PEAK_FP32_TFLOPS if args.precision == 'fp32' else PEAK_16BIT_TFLOPS
     step_flops = BATCH * data.flops(FRAMES)
+    # CUs a launch of the dominant kernel can occupy: one workgroup per CU (its LDS tile), one workgroup per token tile
+    launch_workgroups = None
+    if args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0':
+        launch_workgroups = -(-info.tokens // 160) // launches_per_layer
+    cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    launch_cus = min(launch_workgroups, cus) if launch_workgroups else cus
+    launch_peak = peak * launch_cus / cus
     layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
     traffic, traffic_from = pmc_traffic('layer32_' if layer32 else 'ffn_')
     kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
@@ -381,9 +398,13 @@ def run_c2(args, rank, world, local_rank, use_dist):
             'kernel': kernel_name,
             'bound': 'mfma',
             'achieved': ffn_tflops,
-            'peak': peak,
+            'peak': launch_peak,
             'unit': 'TFLOP/s',
-            'frac': ffn_tflops / peak,
+            'frac': ffn_tflops / launch_peak,
+            'peak_scope': f'{launch_cus} of {cus} CUs: a launch is {launch_workgroups or "?"} workgroups, one per CU '
+                          f'({pipelines} pipeline(s) of the batch run beside each other); whole-chip dense peak {peak}',
+            'frac_of_whole_chip': ffn_tflops / peak,
+            'pipelines': pipelines,
             'traffic': traffic,
             'traffic_from': traffic_from and f'{traffic_from} (committed rocprofv3 --pmc passes of this command, '
                                              'not this run)',
@@ -404,7 +425,10 @@ def run_c2(args, rank, world, local_rank, use_dist):
     if alt_x2:
         line['alt_precision_fp16x2'] = alt_x2
     if alt_streams:
-        line['alt_streams'] = alt_streams
+        # the one-pipeline run's layer launches are whole-batch launches on the whole chip
+        alt_streams['roofline_frac_whole_chip'] = (ffn_flops * launches_per_layer / (1e-3 * alt_streams['mean_launch_ms'])
+                                                   / 1e12 / peak)
+        line['alt_single_pipeline'] = alt_streams
     if world == 1 and not args.no_cpu:
         line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
         line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
@@ -483,12 +507,16 @@ def run_c4(args, rank, world, local_rank, use_dist):
     total_frames = sum(frames)
     # FLOPs of my own shard's launches (rank 0's) for the roofline of its layer kernel
     processed = 0
+    chip_share = 0.0                 # sum over batches of frames / pipelines: a launch of a p-pipeline batch holds 1/p of the CUs
     for batch in batches:
         lens = [frames[mine[j]] for j in batch]
         _, info = E.plan_windows(len(batch), max(lens), lens)
         processed += info.processed_frames
+        chip_share += info.processed_frames / model.pipelines(info.tokens)
     per_frame = 4.0 * HIDDEN * FFN + 2.0 * HIDDEN * HIDDEN + 6.0 * HIDDEN * HIDDEN * (LAYERS - 1) / LAYERS
-    ffn_tflops = per_frame * processed * LAYERS * args.steps / (1e-3 * ffn_ms) / 1e12 if ffn_ms else 0.0
+    # launch durations are summed over both pipelines of a split batch: weight them by the share of the chip a launch holds
+    chip_ms = ffn_ms * chip_share / max(processed, 1)
+    ffn_tflops = per_frame * processed * LAYERS * args.steps / (1e-3 * chip_ms) / 1e12 if ffn_ms else 0.0
     peak = PEAK_FP32_TFLOPS if args.precision == 'fp32' else PEAK_16BIT_TFLOPS
     padded_frames = sum(len(b) * max(frames[mine[j]] for j in b) for b in batches)
     return {
@@ -520,6 +548,7 @@ def run_c4(args, rank, world, local_rank, use_dist):
             'bound': 'mfma', 'achieved': ffn_tflops, 'peak': peak, 'unit': 'TFLOP/s',
             'frac': ffn_tflops / peak, 'traffic': None,
             'mean_launch_ms': ffn_ms / max(ffn_launches, 1), 'timed_launches': ffn_launches,
+            'chip_share_of_a_launch': chip_share / max(processed, 1),
         },
     }
 

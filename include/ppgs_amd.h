@@ -395,6 +395,13 @@ int ppg_grid_sample(int device, const float* ppg, int rows, int frames,
  * PPGS_AMD_CHECK_FINITE=1) so that NaN posteriors never leave silently.
  */
 int ppg_engine_nonfinite(PpgEngine* engine, int clear, int* flag);
+/*
+ * Pipelines a batch whose window plan has `tokens` token rows (PpgPlanInfo.tokens) is split into: the windows of a
+ * batch are independent, so a batch of at least 128 rows per CU runs as two half-batches on two HIP streams of the
+ * engine (forked from and joined into the caller's stream; the results are bit-identical to one pipeline).
+ * PPGS_AMD_STREAMS=1 at engine creation turns the split off.  No reference counterpart (one CUDA stream).
+ */
+int ppg_engine_pipelines(const PpgEngine* engine, int tokens);
 int ppg_engine_profile(PpgEngine* engine, int classes);
 int ppg_engine_profile_read(PpgEngine* engine, int kernel_class,
                             double* total_ms, int64_t* launches);

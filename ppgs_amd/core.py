@@ -28,6 +28,8 @@ from . import config, data, engine, load, preprocess
 #   'bf16'  bf16 operands (the benchmark configuration of BASELINE.json; ~2-3e-3, which is what
 #           the reference's own bf16 autocast loses, fixture g7_glue)
 #   'fp32'  f32-input MFMA, the parity mode (<= 1e-4)
+#   'fp16x2' every operand as an fp16 hi + lo pair, three fp16 MFMAs per product: ~3e-6 from the fp32
+#           reference at a third of the fp32 mode's time
 CHECK_FINITE = os.environ.get('PPGS_AMD_CHECK_FINITE', '0') != '0'
 PRECISION = os.environ.get('PPGS_AMD_PRECISION', 'fp16')
 

@@ -280,9 +280,11 @@ struct PpgEngine {
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
-    int num_streams = 1;    // pipelines a large batch is split into (PPGS_AMD_STREAMS; 2 = +3..8 % at C2,
-                            // but kernels of the two halves then overlap and per-kernel timings blur)
+    int num_streams = 2;    // pipelines (HIP streams) a batch of >= 128 x CUs token rows is split into (PPGS_AMD_STREAMS;
+                            // 2 = +4..6.5 % at C2 over one pipeline, bit-identical: the half-batches' kernels run beside each
+                            // other, every launch on the CUs its one-per-CU workgroups occupy)
     std::vector<hipStream_t> side_streams;
+    int stream_offset_us = 0;  // PPGS_AMD_STREAM_OFFSET_US: pipeline i of a split batch starts i * this late
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
     int l32_debug = 0, h32_debug = 0;         // PPGS_AMD_L32_DEBUG / PPGS_AMD_H32_DEBUG: phase-skipping switches of the timing experiments (wrong results), read once
@@ -506,6 +508,14 @@ void choose_ffn_tiling(const PpgEngine* e, int M, int* nt_out, int* splits_out) 
     }
     *nt_out = nt;
     *splits_out = splits;
+}
+
+// One wave that holds its stream for `ticks` of the 100 MHz real-time counter: the phase offset between the two
+// pipelines of a split batch (PPGS_AMD_STREAM_OFFSET_US) -- every workgroup of a layer kernel reads its inputs at the
+// launch's start and writes Q / K / V at its end, so two pipelines in phase hit the memory system together.
+__global__ void phase_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
@@ -914,6 +924,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
     if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
+    if (const char* s = getenv("PPGS_AMD_STREAM_OFFSET_US")) e->stream_offset_us = std::max(0, atoi(s));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < e->num_streams; ++i) {
         hipStream_t st;
@@ -1383,6 +1394,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     for (size_t gi = 1; gi < ngroups; ++gi) {
         hipStream_t side = e->side_streams[gi - 1];
         HIP_OK(hipStreamWaitEvent(side, e->ev_fork, 0));
+        if (e->stream_offset_us > 0)
+            hipLaunchKernelGGL(phase_delay_kernel, dim3(1), dim3(64), 0, side, (unsigned long long)(100ull * e->stream_offset_us * gi));
         if ((rc = run_group(plan.groups[gi], side))) return rc;
         HIP_OK(hipEventRecord(e->ev_join[gi - 1], side));
     }
@@ -2239,6 +2252,11 @@ int ppg_engine_nonfinite(PpgEngine* e, int clear, int* flag) {
     if (value && clear) HIP_OK(hipMemset(e->d_overflow, 0, sizeof(value)));
     *flag = (int)value;
     return PPG_OK;
+}
+
+int ppg_engine_pipelines(const PpgEngine* e, int tokens) {
+    if (!e || tokens < 0) return 0;
+    return group_count(e, tokens);
 }
 
 int ppg_engine_profile(PpgEngine* e, int enable) {

@@ -1280,8 +1280,15 @@ template <class P>
 __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int splits) {
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+#if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 4
+    const int m = slot;
+#else
     const int m = a.rowmap ? a.rowmap[slot >> 4] + (slot & 15) : slot;          // (row map: only the rows of the step)
+#endif
     if (m >= a.M) return;
+#if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 3
+    if (m >= 0) return;
+#endif
     const int H = a.H;
     float4 v[2];
     float sum = 0.f;
@@ -1305,9 +1312,11 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
                 for (int j = 0; j < N; ++j) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
             }
         };
+#if !defined(PPG_REDUCE_ABL) || PPG_REDUCE_ABL != 1
         batch(std::integral_constant<int, 8>{});
         batch(std::integral_constant<int, 4>{});
         batch(std::integral_constant<int, 1>{});
+#endif
         v[h] = acc;
         sum += (acc.x + acc.y) + (acc.z + acc.w);
     }
@@ -1330,6 +1339,9 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
         const float y1 = (v[h].y - mean) * rstd * gv.y + ev.y;
         const float y2 = (v[h].z - mean) * rstd * gv.z + ev.z;
         const float y3 = (v[h].w - mean) * rstd * gv.w + ev.w;
+#if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 2
+        if (y0 != 12345.678f) continue;
+#endif
         *reinterpret_cast<float4*>(a.X + (size_t)m * H + n) = make_float4(y0, y1, y2, y3);
         if constexpr (P::kIsBF16 || P::kSplit) store4<P>(a.Xb + (size_t)m * H * P::kBytes + P::row_byte(n), y0, y1, y2, y3);
     }

@@ -142,6 +142,7 @@ SYMBOLS = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     'ppg_engine_nonfinite': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'ppg_engine_pipelines': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'ppg_stream_create_batch': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'ppg_stream_batch': (ctypes.c_int, [ctypes.c_void_p]),
@@ -330,6 +331,10 @@ class Engine:
         """A KV-cached causal stream over one utterance of up to `max_frames` frames
         (see Stream); the engine must be causal."""
         return Stream(self, max_frames, dtype)
+
+    def pipelines(self, tokens):
+        """HIP streams a batch of `tokens` token rows (PlanInfo.tokens) is split over (1 or 2)."""
+        return int(self._lib.ppg_engine_pipelines(self._handle, int(tokens)))
 
     def nonfinite(self, clear=True):
         """True when a launch of this engine produced a non-finite logit for a valid frame since the
