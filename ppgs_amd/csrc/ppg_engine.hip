@@ -284,6 +284,7 @@ struct PpgEngine {
                             // 2 = +4..6.5 % at C2 over one pipeline, bit-identical: the half-batches' kernels run beside each
                             // other, every launch on the CUs its one-per-CU workgroups occupy)
     std::vector<hipStream_t> side_streams;
+    int stream_min_rows = 128; // PPGS_AMD_STREAMS_MIN_ROWS: token rows per CU from which a batch is split into pipelines
     int stream_offset_us = 0;  // PPGS_AMD_STREAM_OFFSET_US: pipeline i of a split batch starts i * this late
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
@@ -546,7 +547,7 @@ Workspace layout(const PpgEngine* e, int tokens, int vt_tokens) {
 // filled round of workgroups leaves idle (+8 % at C2).
 int group_count(const PpgEngine* e, int tokens) {
     if (e->num_streams <= 1) return 1;
-    return tokens >= 128 * e->num_cus ? e->num_streams : 1;
+    return tokens >= e->stream_min_rows * e->num_cus ? e->num_streams : 1;
 }
 
 size_t finish_plan(const PpgEngine* e, Plan* p) {
@@ -924,6 +925,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
     if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
+    if (const char* s = getenv("PPGS_AMD_STREAMS_MIN_ROWS")) e->stream_min_rows = std::max(1, atoi(s));
     if (const char* s = getenv("PPGS_AMD_STREAM_OFFSET_US")) e->stream_offset_us = std::max(0, atoi(s));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < e->num_streams; ++i) {
@@ -1911,13 +1913,21 @@ struct PpgW2v2Body {
                    char* wo_img; char* w1_img; char* w2_img; };   // fragment images for ppg_gemm32.hip (16-bit modes)
     bool gemm32 = true;            // PPGS_AMD_W2V2_GEMM32=0: linear_kernel<EPI_GENERAL> for every projection
     std::vector<Layer> layer;
-    char* staging = nullptr;       // pinned: window / block / item tables of the call in flight
-    size_t staging_bytes = 0;
-    hipEvent_t uploaded = nullptr;
+    // per pipeline (a batch of >= 8 items runs as two half-batches on two HIP streams, as the PPG network's engine does)
+    struct Slot { char* staging = nullptr; size_t staging_bytes = 0; hipEvent_t uploaded = nullptr; };   // pinned tables of the call in flight
+    Slot slot[2];
+    int pipelines = 2;             // PPGS_AMD_W2V2_STREAMS
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~PpgW2v2Body() {
         (void)hipSetDevice(eng.device);
-        if (staging) (void)hipHostFree(staging);
-        if (uploaded) (void)hipEventDestroy(uploaded);
+        for (Slot& sl : slot) {
+            if (sl.staging) (void)hipHostFree(sl.staging);
+            if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        }
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 
@@ -2021,7 +2031,11 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
         }
     }
 #undef NEED
-    HIP_OK(hipEventCreateWithFlags(&m->uploaded, hipEventDisableTiming));
+    for (PpgW2v2Body::Slot& sl : m->slot) HIP_OK(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+    HIP_OK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    if (const char* v = getenv("PPGS_AMD_W2V2_STREAMS")) m->pipelines = std::max(1, std::min(atoi(v), 2));
     *out = m.release();
     return PPG_OK;
 }
@@ -2054,9 +2068,24 @@ BodyLayout body_layout(const PpgW2v2Body* m, int batch, int frames) {
 }
 }  // namespace
 
+namespace {
+// Items of the first pipeline when the batch is split (0: one pipeline).  Items are independent (one attention
+// window each); the projections' 128-row tiles of 8 192 rows are 192 workgroups on 256 CUs, and two half-batches on
+// two streams run one half's GEMMs beside the other half's attention and LayerNorm launches.
+int body_first_half(const PpgW2v2Body* m, int batch, int frames) {
+    const int R = (frames + 31) / 32 * 32;
+    if (m->pipelines < 2 || batch < 8 || (long)batch * R < 4096) return 0;
+    return (batch + 1) / 2;
+}
+int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* features, const int64_t* valid_frames, int batch, int frames,
+                     float* out, void* workspace, size_t workspace_bytes, hipStream_t s);
+}  // namespace
+
 int ppg_w2v2_body_workspace_bytes(const PpgW2v2Body* body, int batch, int frames, size_t* bytes) {
     if (!body || !bytes || batch <= 0 || frames <= 0) return fail(PPG_EINVAL, "bad argument");
-    *bytes = body_layout(body, batch, frames).total;
+    const int h = body_first_half(body, batch, frames);
+    *bytes = h ? align_up(body_layout(body, h, frames).total, 256) + body_layout(body, batch - h, frames).total
+               : body_layout(body, batch, frames).total;
     return PPG_OK;
 }
 
@@ -2065,27 +2094,47 @@ int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* 
     if (!m || !features || !valid_frames || !out || !workspace || batch <= 0 || frames <= 0) return fail(PPG_EINVAL, "bad argument");
     for (int b = 0; b < batch; ++b)
         if (valid_frames[b] < 1 || valid_frames[b] > frames) return fail(PPG_EINVAL, "valid_frames[%d]=%lld outside [1, %d]", b, (long long)valid_frames[b], frames);
+    size_t need = 0;
+    (void)ppg_w2v2_body_workspace_bytes(m, batch, frames, &need);
+    if (workspace_bytes < need) return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(PPG_EINVAL, "workspace not 256-byte aligned");
+    HIP_OK(hipSetDevice(m->eng.device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int h = body_first_half(m, batch, frames);
+    if (!h) return body_forward_one(m, m->slot[0], features, valid_frames, batch, frames, out, workspace, workspace_bytes, s);
+    const size_t ws0 = align_up(body_layout(m, h, frames).total, 256);
+    HIP_OK(hipEventRecord(m->ev_fork, s));
+    HIP_OK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    int rc = body_forward_one(m, m->slot[1], features + (size_t)h * frames * 512, valid_frames + h, batch - h, frames,
+                              out + (size_t)h * frames * m->hidden, static_cast<char*>(workspace) + ws0, workspace_bytes - ws0, m->side);
+    if (rc) return rc;
+    HIP_OK(hipEventRecord(m->ev_join, m->side));
+    rc = body_forward_one(m, m->slot[0], features, valid_frames, h, frames, out, workspace, ws0, s);
+    HIP_OK(hipStreamWaitEvent(s, m->ev_join, 0));
+    return rc;
+}
+
+namespace {
+int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* features, const int64_t* valid_frames, int batch, int frames,
+                     float* out, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const BodyLayout L = body_layout(m, batch, frames);
     if (workspace_bytes < L.total) return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, L.total);
-    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(PPG_EINVAL, "workspace not 256-byte aligned");
     PpgEngine* E = &m->eng;
-    HIP_OK(hipSetDevice(E->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const int H = m->hidden, F = m->ffn, sz = E->sz, prec = E->cfg.precision, M = L.M, R = L.R;
     char* base = static_cast<char*>(workspace);
 
     // tables: one window per item, every 16-row block of item b -> window b, query tiles of 64
     const size_t table_bytes = L.ln;                           // win | blk | items are the first three regions
-    if (m->staging_bytes < table_bytes) {
-        if (m->staging) { HIP_OK(hipEventSynchronize(m->uploaded)); (void)hipHostFree(m->staging); m->staging = nullptr; }
-        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&m->staging), table_bytes, hipHostMallocDefault));
-        m->staging_bytes = table_bytes;
+    if (slot.staging_bytes < table_bytes) {
+        if (slot.staging) { HIP_OK(hipEventSynchronize(slot.uploaded)); (void)hipHostFree(slot.staging); slot.staging = nullptr; }
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&slot.staging), table_bytes, hipHostMallocDefault));
+        slot.staging_bytes = table_bytes;
     }
-    HIP_OK(hipEventSynchronize(m->uploaded));                  // the previous call's upload has left the staging buffer
-    memset(m->staging, 0, table_bytes);
-    PpgWindow* hw = reinterpret_cast<PpgWindow*>(m->staging + L.win);
-    int* hb = reinterpret_cast<int*>(m->staging + L.blk);
-    AttnItem* hi = reinterpret_cast<AttnItem*>(m->staging + L.items);
+    HIP_OK(hipEventSynchronize(slot.uploaded));                  // the previous call's upload has left the staging buffer
+    memset(slot.staging, 0, table_bytes);
+    PpgWindow* hw = reinterpret_cast<PpgWindow*>(slot.staging + L.win);
+    int* hb = reinterpret_cast<int*>(slot.staging + L.blk);
+    AttnItem* hi = reinterpret_cast<AttnItem*>(slot.staging + L.items);
     int ni = 0;
     for (int b = 0; b < batch; ++b) {
         PpgWindow& w = hw[b];
@@ -2095,8 +2144,8 @@ int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* 
         for (int q0 = 0; q0 < frames; q0 += 64) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, 0, 0};
     }
     HIP_OK(hipMemsetAsync(base + L.ln, 0, L.hid - L.ln, s));    // padding rows, slack columns: finite (masked keys are still multiplied)
-    HIP_OK(hipMemcpyAsync(base, m->staging, table_bytes, hipMemcpyHostToDevice, s));
-    HIP_OK(hipEventRecord(m->uploaded, s));
+    HIP_OK(hipMemcpyAsync(base, slot.staging, table_bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipEventRecord(slot.uploaded, s));
     const PpgWindow* d_win = reinterpret_cast<const PpgWindow*>(base + L.win);
     const int* d_blk = reinterpret_cast<const int*>(base + L.blk);
     const AttnItem* d_items = reinterpret_cast<const AttnItem*>(base + L.items);
@@ -2196,6 +2245,7 @@ int ppg_w2v2_body_forward(PpgW2v2Body* m, const float* features, const int64_t* 
     HIP_OK(hipMemcpy2DAsync(out, (size_t)frames * H * 4, X, (size_t)R * H * 4, (size_t)frames * H * 4, batch, hipMemcpyDeviceToDevice, s));
     return PPG_OK;
 }
+}  // namespace
 
 int ppg_frontend(int device, const float* audio, int batch, int samples, void* spec, void* mel, void* stream) {
     if (!audio || (!spec && !mel)) return fail(PPG_EINVAL, "null argument");
