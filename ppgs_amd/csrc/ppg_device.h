@@ -404,6 +404,9 @@ struct FfnArgs {
     int splits;
     const int* rowmap;        // see GatherArgs (16 tokens per wave, no hidden splits)
     int map_blocks;
+    int* tickets;             // split-hidden mode, 16 tokens per wave, hidden 256, <= 8 splits: one zeroed counter per token tile --
+                              // the LAST of a tile's workgroups to arrive sums the partial rows and applies LayerNorm-2
+                              // itself (no ffn_reduce_ln_kernel launch); null: the two-pass form
 };
 
 // Memory laid out for the feature-split layer kernel (160-token workgroup tiles):

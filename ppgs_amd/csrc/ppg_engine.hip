@@ -284,6 +284,7 @@ struct PpgEngine {
                             // 2 = +4..6.5 % at C2 over one pipeline, bit-identical: the half-batches' kernels run beside each
                             // other, every launch on the CUs its one-per-CU workgroups occupy)
     std::vector<hipStream_t> side_streams;
+    bool stream_one_pass = false; // PPGS_AMD_STREAM_ONE_PASS=1: KV-cached streams run the split-hidden FFN's reduce + LayerNorm inside the FFN launch (last workgroup of a tile by ticket) -- measured slower: its 64 rows are 4 dependent round trips on 4 waves, 43 us against 18 + 18..30
     int stream_min_rows = 128; // PPGS_AMD_STREAMS_MIN_ROWS: token rows per CU from which a batch is split into pipelines
     int stream_offset_us = 0;  // PPGS_AMD_STREAM_OFFSET_US: pipeline i of a split batch starts i * this late
     hipEvent_t ev_fork = nullptr;
@@ -925,6 +926,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
     if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
+    if (const char* s = getenv("PPGS_AMD_STREAM_ONE_PASS")) e->stream_one_pass = atoi(s) != 0;
     if (const char* s = getenv("PPGS_AMD_STREAMS_MIN_ROWS")) e->stream_min_rows = std::max(1, atoi(s));
     if (const char* s = getenv("PPGS_AMD_STREAM_OFFSET_US")) e->stream_offset_us = std::max(0, atoi(s));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -1455,6 +1457,7 @@ struct PpgStream {
     float* probs = nullptr;       // (batch, output_channels, rows)
     int* d_blk = nullptr;
     char* d_tables = nullptr;     // one step's tables (layout: Tables)
+    int* d_tickets = nullptr;     // one-pass split-hidden FFN: a counter per token tile, zero between launches (FfnArgs::tickets)
     size_t qk_bytes = 0, vt_bytes = 0, cache_off = 0, part_off = 0;
     int max_splits = 1;           // hidden splits of the FFN launches (a step's few rows cannot stream the weights through few CUs fast enough)
     std::vector<int> received, x_valid, o_valid;
@@ -1471,7 +1474,7 @@ struct PpgStream {
     unsigned step = 0;
     ~PpgStream() {
         if (e) (void)hipSetDevice(e->device);
-        for (void* p : {(void*)buf, (void*)feats, (void*)probs, (void*)d_blk, (void*)d_tables}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)buf, (void*)feats, (void*)probs, (void*)d_blk, (void*)d_tables, (void*)d_tickets}) if (p) (void)hipFree(p);
         if (staging) (void)hipHostFree(staging);
         for (hipEvent_t ev : uploaded) if (ev) (void)hipEventDestroy(ev);
     }
@@ -1531,6 +1534,11 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     tb.bytes = off;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_tables), tb.bytes));
     HIP_OK(hipMemset(st->d_tables, 0, tb.bytes));
+    if (e->stream_one_pass && c.hidden_channels == 256 && e->ffn_fused) {
+        const size_t tiles = (size_t)tb.max_blocks / 4 + 4;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&st->d_tickets), tiles * sizeof(int)));
+        HIP_OK(hipMemset(st->d_tickets, 0, tiles * sizeof(int)));
+    }
     HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&st->staging), PpgStream::kSlots * tb.bytes, hipHostMallocDefault));
     for (hipEvent_t& ev : st->uploaded) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_OK(hipDeviceSynchronize());
@@ -1691,7 +1699,10 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
         int ffn_splits = 1;
         if (e->ffn_split) {
             const int wgs = (nmap[0] + 3) / 4;
-            const int cap = e->ffn_split_max > 0 ? std::min(e->ffn_split_max, st->max_splits) : st->max_splits;
+            // (one-pass form: the tile's last workgroup sums the partial rows itself, 4 rows x <= 8 splits of loads in
+            // flight per wave; four splits keep that to two round trips)
+            int cap = e->ffn_split_max > 0 ? std::min(e->ffn_split_max, st->max_splits) : st->max_splits;
+            if (st->d_tickets) cap = std::min(cap, e->ffn_split_max > 0 ? 8 : 4);
             while (ffn_splits * 2 <= cap && wgs * ffn_splits * 2 <= e->num_cus) ffn_splits *= 2;
         }
         for (int l = 0; l < c.num_layers; ++l) {
@@ -1727,6 +1738,7 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
                 a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = MT;
                 a.splits = ffn_splits; a.partial = ffn_splits > 1 ? reinterpret_cast<float*>(base + st->part_off) : nullptr;
                 a.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[0]); a.map_blocks = nmap[0];
+                a.tickets = ffn_splits > 1 ? st->d_tickets : nullptr;
                 LAUNCH_OK(ppg::launch_ffn(prec, a, 1, s), "stream ffn");
             }
         }

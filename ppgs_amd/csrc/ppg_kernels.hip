@@ -761,6 +761,51 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 // its third block, so that both run 5 block-phases per chunk -- h of that
 // block travels partner -> owner through LDS once per chunk, its x1 fragments
 // owner -> partner once per launch.
+// Rows m0 .. m0 + R - 1 (dense partial rows slot0 ..) of the split-hidden FFN: b2 + residual + the partial sums in
+// split order, LayerNorm-2, X and its operand copy -- ffn_reduce_ln_kernel's arithmetic, R rows of one wave with all
+// their loads in flight together (hidden 256: a lane owns features 4 lane .. + 3 of every row).
+template <class P, int R>
+__device__ __forceinline__ void reduce_ln_rows(const FfnArgs& a, int splits, int slot0, int m0, int lane, size_t stride) {
+    constexpr int H = 256;
+    const int n = lane * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(a.b2 + n);
+    const float4 gv = *reinterpret_cast<const float4*>(a.gamma + n);
+    const float4 ev = *reinterpret_cast<const float4*>(a.beta + n);
+    float4 xv[R], p[R][8];
+    // the partial rows first: their addresses do not depend on the row map (m0 may still be in flight)
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)      // (unconditional loads: a split past the last re-reads the last one and is not added)
+            p[j][k] = *reinterpret_cast<const float4*>(a.partial + (size_t)min(k, splits - 1) * stride + (size_t)(slot0 + j) * H + n);
+#pragma unroll
+    for (int j = 0; j < R; ++j) xv[j] = *reinterpret_cast<const float4*>(a.X + (size_t)min(m0 + j, a.M - 1) * H + n);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        float4 acc = make_float4(bv.x + xv[j].x, bv.y + xv[j].y, bv.z + xv[j].z, bv.w + xv[j].w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < splits) { acc.x += p[j][k].x; acc.y += p[j][k].y; acc.z += p[j][k].z; acc.w += p[j][k].w; }
+        float sum = (acc.x + acc.y) + (acc.z + acc.w);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        const float mean = sum / (float)H;
+        const float d0 = acc.x - mean, d1 = acc.y - mean, d2 = acc.z - mean, d3 = acc.w - mean;
+        float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+        const float rstd = 1.0f / sqrtf(sq / (float)H + kLnEps);
+        const float y0 = (acc.x - mean) * rstd * gv.x + ev.x;
+        const float y1 = (acc.y - mean) * rstd * gv.y + ev.y;
+        const float y2 = (acc.z - mean) * rstd * gv.z + ev.z;
+        const float y3 = (acc.w - mean) * rstd * gv.w + ev.w;
+        const int m = m0 + j;
+        if (m >= a.M) continue;
+        *reinterpret_cast<float4*>(a.X + (size_t)m * H + n) = make_float4(y0, y1, y2, y3);
+        if constexpr (P::kIsBF16 || P::kSplit) store4<P>(a.Xb + (size_t)m * H * P::kBytes + P::row_byte(n), y0, y1, y2, y3);
+    }
+}
+
 template <class P, int NTA, int NTB, int NBH, bool OP, bool QKV, int ROLE>
 __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int tok0) {
     constexpr int NT = NTB;                         // token blocks of everything outside the chunk loop
@@ -1099,6 +1144,30 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& a, char* smem, const int
                 *reinterpret_cast<float4*>(part + (size_t)pm * H + pair_feature(nb, g)) =
                     make_float4(yacc[nb][t][0], yacc[nb][t][1], yacc[nb][t][2], yacc[nb][t][3]);
         }
+        if constexpr (NT == 1 && NBH == 16 && !OP) {
+            if (a.tickets != nullptr) {
+                // one-pass form: every workgroup of the tile publishes its partial rows (device-scope release) and draws
+                // a ticket; the last one to arrive sees all of them (acquire) and finishes the tile's 64 rows
+                __threadfence();
+                __syncthreads();
+                int* last = reinterpret_cast<int*>(smem);            // (the weight buffers are dead)
+                if (tid == 0) {
+                    const int drawn = atomicAdd(a.tickets + blockIdx.x, 1);
+                    *last = drawn == (int)gridDim.y - 1;
+                    if (*last) a.tickets[blockIdx.x] = 0;            // for the next launch
+                }
+                __syncthreads();
+                if (!*last) return;
+                __threadfence();
+                const int slot0 = (blockIdx.x * 4 + wave) * 16;
+                if (tok0 + 16 <= a.M) {
+#pragma unroll 1
+                    for (int r = 0; r < 16; r += 4) reduce_ln_rows<P, 4>(a, (int)gridDim.y, slot0 + r, tok0 + r, lane, (size_t)prows * H);
+                } else {
+                    for (int r = 0; r < 16 && tok0 + r < a.M; ++r) reduce_ln_rows<P, 1>(a, (int)gridDim.y, slot0 + r, tok0 + r, lane, (size_t)prows * H);
+                }
+            }
+        }
         return;
     }
     // (OP: nothing derived from the lane coordinates before the chunk loop may stay live across it)
@@ -1279,11 +1348,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <class P>
 __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int splits) {
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (wave-uniform by construction; said so, the row-map entry is a scalar load -- it does not queue behind the
+    // vector loads of the partial sums, which return in issue order)
+    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 4
     const int m = slot;
 #else
     const int m = a.rowmap ? a.rowmap[slot >> 4] + (slot & 15) : slot;          // (row map: only the rows of the step)
+#endif
+#if !defined(PPG_REDUCE_ABL)
+    if (a.H == 256 && splits <= 8) {
+        // (the row-map entry and the partial rows travel together; a row past M is computed and not stored)
+        reduce_ln_rows<P, 1>(a, splits, a.rowmap ? slot : min(slot, a.M - 1), m, lane,
+                             (size_t)(a.rowmap ? (a.map_blocks + 3) / 4 * 64 : a.M) * 256);
+        return;
+    }
 #endif
     if (m >= a.M) return;
 #if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 3
@@ -1724,6 +1803,11 @@ hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, blocks, dim3(256), lds, s, a);
     e = hipGetLastError();
     if (e != hipSuccess || !a.partial) return e;
+    if (a.tickets != nullptr) {
+        // (the kernel's one-pass form exists for 16 tokens per wave, hidden 256, no fused out-projection, <= 8 splits)
+        if (NT == 1 && NBH == 16 && !OP && a.splits <= 8) return e;
+        return hipErrorInvalidValue;
+    }
     hipLaunchKernelGGL(ffn_reduce_ln_kernel<P>, dim3(a.rowmap ? a.map_blocks * 4 : (a.M + 3) / 4), dim3(256), 0, s, a, a.splits);
     return hipGetLastError();
 }

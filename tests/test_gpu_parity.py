@@ -823,20 +823,39 @@ def test_large_ragged_batch_and_legacy_mode():
         fp32.encode(torch.zeros(1, 80, 5000).half().cuda(), [5000], legacy_mode=True)
 
 
-def test_multi_stream_groups_agree(monkeypatch):
-    """PPGS_AMD_STREAMS=2: the batch is split into two window groups run as
-    independent pipelines on two HIP streams; same results as one stream."""
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_two_pipelines_equal_one(monkeypatch, precision):
+    """A batch of >= 128 token rows per CU runs as two half-batches on two HIP streams of the engine (the default,
+    ppg_engine_pipelines); PPGS_AMD_STREAMS=1 is one pipeline.  Windows are independent: a uniform batch gives the
+    same bits in the 16-bit modes; in a ragged one the planner may give a short window the other attention tile width (it ranks the
+    windows of a pipeline), which moves the result by rounding of the operand format only."""
     state = W.seeded_state_dict(seed=1234)
     gen = torch.Generator().manual_seed(21)
-    lengths = [1000] * 30 + [730, 129]
     feats = torch.randn(32, 80, 1000, generator=gen).half().cuda()
-    single = E.Engine(state, 0, 'fp32').encode(feats, lengths)
-    monkeypatch.setenv('PPGS_AMD_STREAMS', '2')
-    double_engine = E.Engine(state, 0, 'fp32')
-    _, info = E.plan_windows(32, 1000, lengths, engine=double_engine)
-    double = double_engine.encode(feats, lengths)
-    torch.cuda.synchronize()
-    assert (single - double).abs().max() < 5e-6
+    double_engine = E.Engine(state, 0, precision)
+    monkeypatch.setenv('PPGS_AMD_STREAMS', '1')
+    single_engine = E.Engine(state, 0, precision)
+    monkeypatch.delenv('PPGS_AMD_STREAMS')
+    for lengths, exact in (([1000] * 32, True), ([1000] * 30 + [730, 129], False)):
+        _, info = E.plan_windows(32, 1000, lengths, engine=double_engine)
+        assert double_engine.pipelines(info.tokens) == 2 and double_engine.pipelines(10240) == 1
+        assert single_engine.pipelines(info.tokens) == 1
+        double = double_engine.encode(feats, lengths)
+        single = single_engine.encode(feats, lengths)
+        torch.cuda.synchronize()
+        if exact and precision != 'fp32':
+            assert torch.equal(single, double)
+        else:
+            # (fp32 mode = the token-split kernels: a workgroup walks the hidden chunks from an offset of its own
+            # index, so the fp32 sums of a row depend on where its tile lands -- last-bit differences)
+            assert (single - double).abs().max() < (5e-6 if precision == 'fp32' else TOL[precision])
+        # ... and again on a side stream of the caller (the fork and the join are relative to the caller's stream)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            again = double_engine.encode(feats, lengths)
+        side.synchronize()
+        assert torch.equal(again, double)
 
 
 def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
@@ -1008,6 +1027,24 @@ def test_w2v2_body_shapes_vs_hf_modules():
         out = body(x, valid)
         for item, count in enumerate(valid):
             assert (out[item, :count] - ref[item, :count]).abs().max() < 1e-4, (shape, item)
+
+
+def test_w2v2_body_two_pipelines_equal_one(monkeypatch):
+    """A batch of >= 8 items (>= 4096 rows) runs as two half-batches on two HIP streams of the body
+    (PPGS_AMD_W2V2_STREAMS=1: one): the same bits, odd batch sizes and ragged masks included."""
+    import transformers
+    transformers.utils.logging.set_verbosity_error()
+    torch.manual_seed(5)
+    model = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(num_hidden_layers=2)).eval().cuda()
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(9, 499, 512, generator=gen).cuda()
+    valid = [499, 400, 499, 1, 257, 499, 33, 480, 499]
+    double = E.W2v2Body(model, 0, 'bf16')(x, valid)
+    monkeypatch.setenv('PPGS_AMD_W2V2_STREAMS', '1')
+    single = E.W2v2Body(model, 0, 'bf16')(x, valid)
+    torch.cuda.synchronize()
+    for item, count in enumerate(valid):
+        assert torch.equal(single[item, :count], double[item, :count]), item
 
 
 @pytest.mark.parametrize('total', [1130, 780, 501, 2470])
