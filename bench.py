@@ -36,7 +36,7 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the
 layer kernel): algorithmic FLOPs per launch / its mean launch duration
 measured with HIP events on the launch stream inside the timed region.
 The engine runs a batch of this size as TWO pipelines (half-batches on two HIP
-streams, bit-identical to one): a layer launch is then 128 one-per-CU workgroups,
+streams; the same bits at this batch): a layer launch is then 128 one-per-CU workgroups,
 its ceiling is the MFMA peak of the 128 CUs it can occupy (`roofline.peak`,
 `peak_scope`; `frac_of_whole_chip` beside it), and `alt_single_pipeline` is the
 same step with PPGS_AMD_STREAMS=1, where a launch has the whole chip.

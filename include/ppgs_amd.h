@@ -398,7 +398,9 @@ int ppg_engine_nonfinite(PpgEngine* engine, int clear, int* flag);
 /*
  * Pipelines a batch whose window plan has `tokens` token rows (PpgPlanInfo.tokens) is split into: the windows of a
  * batch are independent, so a batch of at least 128 rows per CU runs as two half-batches on two HIP streams of the
- * engine (forked from and joined into the caller's stream; the results are bit-identical to one pipeline).
+ * engine (forked from and joined into the caller's stream; the results equal one pipeline's: bit for bit for a uniform batch in the
+ * 16-bit modes, within the operand format's rounding otherwise -- the planner ranks a pipeline's windows for the attention tile
+ * width, the fp32 mode's kernels sum hidden chunks from a tile-dependent start).
  * PPGS_AMD_STREAMS=1 at engine creation turns the split off.  No reference counterpart (one CUDA stream).
  */
 int ppg_engine_pipelines(const PpgEngine* engine, int tokens);

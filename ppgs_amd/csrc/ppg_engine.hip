@@ -281,7 +281,7 @@ struct PpgEngine {
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 2;    // pipelines (HIP streams) a batch of >= 128 x CUs token rows is split into (PPGS_AMD_STREAMS;
-                            // 2 = +4..6.5 % at C2 over one pipeline, bit-identical: the half-batches' kernels run beside each
+                            // 2 = +4..6.5 % at C2 over one pipeline, the same bits there: the half-batches' kernels run beside each
                             // other, every launch on the CUs its one-per-CU workgroups occupy)
     std::vector<hipStream_t> side_streams;
     bool stream_one_pass = false; // PPGS_AMD_STREAM_ONE_PASS=1: KV-cached streams run the split-hidden FFN's reduce + LayerNorm inside the FFN launch (last workgroup of a tile by ticket) -- measured slower: its 64 rows are 4 dependent round trips on 4 waves, 43 us against 18 + 18..30

@@ -906,6 +906,21 @@ def test_graphed_encode_helper():
         assert (out - ref).abs().max() == 0
 
 
+def test_graph_capture_spans_both_pipelines():
+    """A batch that runs as two pipelines, captured: the fork to the engine's second stream and the join are
+    part of the HIP graph, and a replay equals the eager call."""
+    engine, state = eng(precision='bf16')
+    _, info = E.plan_windows(32, 1000, [1000] * 32, engine=engine)
+    assert engine.pipelines(info.tokens) == 2
+    gen = torch.Generator().manual_seed(9)
+    run = engine.graphed(32, 1000)
+    for _ in range(2):
+        feats = torch.randn(32, 80, 1000, generator=gen).half().cuda()
+        out = run(feats).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out, engine.encode(feats, [1000] * 32))
+
+
 def test_plan_cache_eviction_and_graph_replay():
     """More than 64 distinct batch shapes pass through one engine (every ragged
     batch of a file job is a new shape): evictions must not touch the plan a
