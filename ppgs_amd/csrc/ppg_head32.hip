@@ -97,36 +97,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
     };
 
-    // ---- window metadata of everything this thread touches, FIRST and with unconditional loads on clamped indices: the
-    // gathered row of the thread (token m0 - HALO + tid) and the lane's token of every token block.  Two dependent
-    // hops (block -> window record) for all of them together; behind the gather's 96 loads (a wave's vector loads
-    // return in issue order) and under `if` they were four hops, 8 k of the kernel's 83 k cycles.
-    struct Meta { int w, tt, frames, valid; };
-    auto meta_of = [&](int m) {
-        const int blk = a.blk_win[min(max(m, 0), a.M - 1) >> 4];
-        const PpgWindow* wp = a.win + max(blk, 0);
-        Meta r;
-        const int tok_off = wp->tok_off;
-        r.frames = wp->frames; r.valid = wp->valid;
-        r.w = (m >= 0 && m < a.M) ? blk : -1;
-        r.tt = m - tok_off;
-        return r;
-    };
-    const int mrow = m0 - HALO + tid;
-    const Meta rm = meta_of(mrow);
-    const PpgWindow wrow = a.win[max(rm.w, 0)];
-    Meta tmv[TB];
-#pragma unroll
-    for (int t = 0; t < TB; ++t) tmv[t] = meta_of(m0 + 32 * t + tok);
-
     // ---- 1. gather: thread r < TOKS + 2 HALO takes row r = token m0 - HALO + r, all channels (for one channel,
     // neighbouring threads read neighbouring frames)
     if (tid < TOKS + 2 * HALO && !(a.debug_mode & 4)) {
+        const int m = m0 - HALO + tid;
         int frame = -1;
         size_t base = 0;
-        if (rm.w >= 0 && rm.tt < rm.frames) {
-            frame = wrow.chunked ? max(wrow.start + rm.tt - a.overlap, 0) : rm.tt;
-            base = (size_t)wrow.item * a.C * a.T;
+        if (m >= 0) {
+            const TokMeta tm = tok_meta(a.blk_win, a.win, m, a.M);
+            if (tm.w >= 0 && tm.tt < tm.frames) {
+                const PpgWindow w = a.win[tm.w];
+                frame = w.chunked ? max(w.start + tm.tt - a.overlap, 0) : tm.tt;
+                base = (size_t)w.item * a.C * a.T;
+            }
         }
         // every load is issued unconditionally (a dead row reads frame 0 of item 0, a padding channel re-reads the last
         // one) and masked afterwards: predicated loads came out as 96 branches with a wait each, 51 k cycles of this
@@ -159,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned edge[TB];                               // wave-uniform: bit tap = some lane's tap leaves its window
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
-        const Meta& tm = tmv[t];
+        const TokMeta tm = tok_meta(a.blk_win, a.win, m0 + 32 * t + tok, a.M);
         live[t] = tm.w >= 0 && tm.tt < tm.frames;
         valid[t] = live[t] && tm.tt < tm.valid;
         tt[t] = live[t] ? tm.tt : 0;
