@@ -852,7 +852,7 @@ int frontend_for(int device, Frontend** out) {
         if ((rc = up(img.data(), img.size() * 2, (const void**)&f.tb.mel_img))) return rc;
         if ((rc = up(prog.data(), prog.size() * 4, (const void**)&f.tb.mel_prog))) return rc;
         f.tb.dbg = nullptr;
-        if (getenv("PPGS_AMD_FE_TIMING")) {
+        if (getenv("PPGS_AMD_FE_TIMING") || getenv("PPGS_AMD_FE_CHECK")) {
             std::vector<unsigned long long> zeros(64, 0);
             if ((rc = up(zeros.data(), 512, (const void**)&f.tb.dbg))) return rc;
         }
@@ -2288,7 +2288,20 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
         return fail(PPG_EINVAL, "frontend: batch %d x 513 bins x %d frames does not fit the kernel's 32-bit output index", batch, samples / 160);
     hipError_t he = ppg::launch_frontend(f->tb, audio, batch, samples, spec, mel, s);
     if (on) (void)hipEventRecord(ev.b, s);
-    if (f->tb.dbg) {
+    if (f->tb.dbg && getenv("PPGS_AMD_FE_CHECK")) {
+        unsigned long long h[64];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, f->tb.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && (h[0] || h[1] || h[2] || h[4] || getenv("PPGS_AMD_FE_CHECK_VERBOSE"))) {
+            fprintf(stderr, "frontend check: %llu transforms checked, %llu dwords of a repeated transform differ from the first\n", h[3], h[4]);
+            fprintf(stderr, "frontend check: %llu twiddle reads and %llu sample reads from LDS differ from memory, %llu pass-3 inputs differ from the writers' registers\n", h[0], h[1], h[2]);
+            for (int n = 0; n < 6 && n < (int)h[2]; ++n)
+                fprintf(stderr, "   pass-3 input (m, jj, lane, pair) %llu: got %08llx %08llx want %08llx %08llx (workgroup*1000+round %llu)\n", h[32 + 4 * n], h[33 + 4 * n] >> 32, h[33 + 4 * n] & 0xffffffffull,
+                        h[34 + 4 * n] >> 32, h[34 + 4 * n] & 0xffffffffull, h[35 + 4 * n]);
+            for (int n = 0; n < 6 && n < (int)h[0]; ++n)
+                fprintf(stderr, "   twiddle %llu: got %08llx %08llx want %08llx %08llx (workgroup*1000+round %llu)\n", h[8 + 4 * n], h[9 + 4 * n] >> 32, h[9 + 4 * n] & 0xffffffffull,
+                        h[10 + 4 * n] >> 32, h[10 + 4 * n] & 0xffffffffull, h[11 + 4 * n]);
+            (void)hipMemset(f->tb.dbg, 0, 512);
+        }
+    } else if (f->tb.dbg) {
         static int dumps = 0;
         unsigned long long h[64];
         if (dumps++ < 2 && hipStreamSynchronize(s) == hipSuccess &&

@@ -59,7 +59,7 @@ constexpr int OFF_SEG = OFF_TW + 64 * 8;                    // float[2][SEGP]
 constexpr int OFF_FFT = OFF_SEG + 2 * SEGP * 4;             // float2[4][BUF]
 constexpr int OFF_MAG = OFF_FFT + 4 * BUF * 8;              // fp16 rows [16][MROW / 2]
 constexpr int LDS_BYTES = OFF_MAG + FPB * MROW;
-static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
+static_assert(2 * LDS_BYTES <= 163840 && LDS_BYTES % 16 == 0, "two teams per workgroup, the workgroup = the CU's LDS");
 static_assert(OFF_MAG % 16 == 0 && MROW % 16 == 0, "fragment reads are 16-byte aligned");
 
 // Complex arithmetic on (re, im) register pairs with the packed fp32 instructions.  Swapping or negating
@@ -69,6 +69,11 @@ static_assert(OFF_MAG % 16 == 0 && MROW % 16 == 0, "fragment reads are 16-byte a
 typedef float cplx __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return a + b; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return a - b; }
+#ifdef PPG_FE_PLAIN_COMPLEX
+__device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) { return cplx{a.x + b.y, a.y - b.x}; }
+__device__ __forceinline__ cplx csub_mi(cplx a, cplx b) { return cplx{a.x - b.y, a.y + b.x}; }
+__device__ __forceinline__ cplx cmul(cplx a, cplx w) { return cplx{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+#else
 // a + (-i) b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) {
     cplx r;
@@ -88,6 +93,7 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
 }
+#endif
 
 // forward 4-point DFT, in place: (A, B, C, D) -> (X0, X1, X2, X3); CMI: the input C is (-i) C
 template <bool CMI = false>
@@ -132,25 +138,41 @@ __device__ __forceinline__ void dft16(cplx (&x)[16]) {
 
 __device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
 
-// LDS exchanges between the lanes of one wave: hardware executes a wave's LDS
-// operations in order; this only stops the compiler from moving them.
+// LDS exchanges between the lanes of one wave.  The writes must have COMPLETED before another lane's read of them
+// is issued: lgkmcnt(0).  (Round 2 relied on "a wave's LDS operations execute in order" and only stopped the
+// compiler from moving them; that holds on a quiet CU and fails beside another kernel's LDS traffic -- a frame
+// pair whose conjugate-symmetry split read the partner bins of the previous pass, tools/frontend_race_probe.py.)
 __device__ __forceinline__ void wave_sync() {
+#ifndef PPG_FE_NO_LGKM_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
 // SPEC: also store the linear magnitudes (tests, ppg_frontend with a spectrogram pointer); its 18 extra row
 // addresses per lane cost the product instantiation ~200 spilled registers when it was a run-time branch
+//
+// A workgroup is TWO such four-wave teams (512 threads, 2 x 79.5 KiB of LDS = the whole CU): the occupancy of two
+// 256-thread workgroups per CU, and no other kernel's workgroup can share the CU.  That is a correctness matter:
+// beside the encoder's kernels on another stream (attention's 64 KiB workgroups fit next to one 80 KiB workgroup) a
+// frame pair's transform came out wrong about once per 300 pairs -- one VALU result of 16 or 64 lanes, different on
+// a repeat of the same transform from the same LDS inputs (tools/frontend_race_probe*.py, -DPPG_FE_CHECK: samples,
+// twiddles and the pass-2 -> pass-3 exchange verified intact, workgroup barriers between the passes and plain C++
+// complex arithmetic change nothing, a CU of its own gives 0 of 240 launches wrong against 160).  The two teams
+// share nothing but the barriers.
 template <bool SPEC>
-__global__ __launch_bounds__(256, 2) void frontend_kernel(
+__global__ __launch_bounds__(512, 1) void frontend_kernel(
     ppg::FrontendTables tb, const float* __restrict__ audio, int samples, int frames,
     int groups_per_row, int total_groups, int wide_ok, __half* __restrict__ spec, __half* __restrict__ mel)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    char* smem = smem_all + team * LDS_BYTES;
     cplx* tw = reinterpret_cast<cplx*>(smem + OFF_TW);
     float* seg0 = reinterpret_cast<float*>(smem + OFF_SEG);
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cplx* buf = reinterpret_cast<cplx*>(smem + OFF_FFT) + wave * BUF;
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
         const float* arow = audio + (size_t)b * samples;
         const uint32_t dst = lds_addr(seg0) + into * (SEGP * 4);
         const int first = f0 * HOP - PADR;
-        if (wide_ok && first >= 0 && first + SEGP <= samples) {
+        if ((wide_ok & 1) && first >= 0 && first + SEGP <= samples) {
 #pragma unroll
             for (int j = 0; j < (SEGP / 256 + 3) / 4; ++j) {
                 const int piece = wave + 4 * j;
@@ -213,8 +235,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                          :: "v"(p), "s"(__builtin_amdgcn_readfirstlane(dst + piece * 256)) : "memory", "m0");
         }
     };
-    const int stride = gridDim.x;
-    if ((int)blockIdx.x < total_groups) stage(blockIdx.x, 0);
+    const int stride = 2 * gridDim.x;
+    const int first_group = 2 * blockIdx.x + team;
+    if (first_group < total_groups) stage(first_group, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 #ifdef PPG_FE_TIMING
@@ -226,9 +249,14 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
     auto stamp = [&](int) {};
 #endif
     int half = 0;
-    for (int grp = blockIdx.x; grp < total_groups; grp += stride, half ^= 1) {
-        const int b = grp / groups_per_row;
-        const int f0 = (grp - b * groups_per_row) * FPB;
+    // (both teams make the same number of trips -- the barriers are the workgroup's; a team past its last group
+    // runs an empty trip: every frame of it lies past the row's end, nothing is transformed or stored)
+    const int trips = (total_groups - 2 * (int)blockIdx.x + stride - 1) / stride;
+    int grp = first_group;
+    for (int trip = 0; trip < trips; ++trip, grp += stride, half ^= 1) {
+        const bool active = grp < total_groups;
+        const int b = active ? grp / groups_per_row : 0;
+        const int f0 = active ? (grp - b * groups_per_row) * FPB : frames;
         const float* seg = seg0 + half * SEGP;
         // (row pitch of the outputs, hidden from loop-invariant code motion: the compiler otherwise
         // keeps -- and spills -- one 64-bit offset per output row a lane may ever store to)
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
         stamp(1);
 
         // one frame pair (fa, fa + 1) = pair j of the group
-        auto transform = [&](const int j) {
+        auto transform = [&](const int j, const bool verify = false) {
             const int fa = f0 + 2 * j;
             if (fa >= frames) return;
             cplx x[16];
@@ -253,6 +281,17 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                 for (int i = 0; i < 16; ++i) {
                     x[i] = cplx{sa[64 * i], sa[64 * i + HOP]} * hreg[i];
                 }
+#ifdef PPG_FE_CHECK
+                {
+                    const int first = f0 * HOP - PADR;
+                    if (tb.dbg && first >= 0 && first + SEGP <= samples) {
+                        const float* src = audio + (size_t)b * samples + first + (2 * j) * HOP + lane;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (sa[64 * i] != src[64 * i] || sa[64 * i + HOP] != src[64 * i + HOP]) atomicAdd(tb.dbg + 1, 1ull);
+                    }
+                }
+#endif
                 dft16(x);
 #pragma unroll
                 for (int k = 1; k < 16; ++k) x[k] = cmul(x[k], t1[k]);
@@ -270,6 +309,18 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                 for (int i = 0; i < 16; ++i) x[i] = buf[p0 + 68 * i];           // pad(l + 64 i)
                 dft16(x);
                 const int p = lane >> 4, q = lane & 15;
+#ifdef PPG_FE_CHECK
+#pragma unroll
+                for (int k = 1; k < 16; ++k) {
+                    const cplx w = tw[p * k];
+                    const float2 ref = tb.twiddle[16 * p * k];
+                    if (tb.dbg && (w.x != ref.x || w.y != ref.y)) {
+                        const unsigned long long n = atomicAdd(tb.dbg, 1ull);
+                        if (n < 6) { tb.dbg[8 + 4 * n] = (unsigned long long)(p * k); tb.dbg[9 + 4 * n] = ((unsigned long long)__float_as_uint(w.x) << 32) | __float_as_uint(w.y);
+                                     tb.dbg[10 + 4 * n] = ((unsigned long long)__float_as_uint(ref.x) << 32) | __float_as_uint(ref.y); tb.dbg[11 + 4 * n] = (unsigned long long)blockIdx.x * 1000 + grp / stride; }
+                    }
+                }
+#endif
 #pragma unroll
                 for (int k = 1; k < 16; ++k) x[k] = cmul(x[k], tw[p * k]);       // W1024^(16 p k)
                 cplx* dst = buf + q + 272 * p;                                  // pad(q + 256 p + 16 k) = q + 272 p + 17 k
@@ -277,6 +328,30 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                 for (int k = 0; k < 16; ++k) dst[17 * k] = x[k];
             }
             wave_sync();
+#ifdef PPG_FE_CHECK
+            // what pass 3 is about to read against what the writer lanes hold in registers (shuffles: not LDS memory)
+            if (tb.dbg) {
+                if (lane == 0) atomicAdd(tb.dbg + 3, 1ull);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const cplx got = buf[p0 + 68 * m + 272 * jj];
+                        cplx want = cplx{0.f, 0.f};
+#pragma unroll
+                        for (int gsel = 0; gsel < 4; ++gsel) {
+                            const float tx = __shfl(x[gsel + 4 * m].x, 16 * jj + (lane & 15));
+                            const float ty = __shfl(x[gsel + 4 * m].y, 16 * jj + (lane & 15));
+                            if ((lane >> 4) == gsel) want = cplx{tx, ty};
+                        }
+                        if (__float_as_uint(got.x) != __float_as_uint(want.x) || __float_as_uint(got.y) != __float_as_uint(want.y)) {
+                            const unsigned long long n = atomicAdd(tb.dbg + 2, 1ull);
+                            if (n < 6) { tb.dbg[32 + 4 * n] = (unsigned long long)(m * 1000000 + jj * 10000 + lane * 100 + j); tb.dbg[33 + 4 * n] = ((unsigned long long)__float_as_uint(got.x) << 32) | __float_as_uint(got.y);
+                                         tb.dbg[34 + 4 * n] = ((unsigned long long)__float_as_uint(want.x) << 32) | __float_as_uint(want.y); tb.dbg[35 + 4 * n] = (unsigned long long)blockIdx.x * 1000 + grp / stride; }
+                        }
+                    }
+            }
+#endif
             // pass 3: radix 4, stride 256, no twiddles; lane l owns q = l + 64 m
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -306,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                 ha = __float2half_rn(__builtin_amdgcn_sqrtf(ar * ar + ai * ai + 1e-6f));
                 hb = __float2half_rn(__builtin_amdgcn_sqrtf(br * br + bi * bi + 1e-6f));
                 if constexpr (SPEC) {
+                    if (verify) return;
                     spec[(uint32_t)(b * NBINS + k) * (uint32_t)pitch + (uint32_t)fa] = ha;
                     if (fa + 1 < frames) spec[(uint32_t)(b * NBINS + k) * (uint32_t)pitch + (uint32_t)fa + 1u] = hb;
                 }
@@ -317,8 +393,15 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
                 const uint32_t pk = (uint32_t)__half_as_ushort(ha) | ((uint32_t)__half_as_ushort(hb) << 16);
                 const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xB1, 0xf, 0xf, true);   // lane ^ 1
                 const uint32_t val = __builtin_amdgcn_perm(pk, other, sel);
+#ifdef PPG_FE_CHECK
+                if (verify) {          // second computation of the same pair: must reproduce what the first one stored
+                    if (tb.dbg && *reinterpret_cast<uint32_t*>(wdst + 128 * r) != val) atomicAdd(tb.dbg + 4, 1ull);
+                    continue;
+                }
+#endif
                 *reinterpret_cast<uint32_t*>(wdst + 128 * r) = val;
             }
+            if (verify) return;
             if (lane == 0) {                                        // k = 512
                 __half ha, hb;
                 split_bin(8, ha, hb);
@@ -328,10 +411,16 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
         };
 
         transform(wave);
+#ifdef PPG_FE_CHECK
+        transform(wave, true);
+#endif
         stamp(2);
-        if (grp + stride < total_groups) stage(grp + stride, half ^ 1);    // free since the barrier above: it held the previous group
+        if (!(wide_ok & 4) && grp + stride < total_groups) stage(grp + stride, half ^ 1);    // free since the barrier above: it held the previous group
         stamp(3);
         transform(wave + 4);
+#ifdef PPG_FE_CHECK
+        transform(wave + 4, true);
+#endif
         stamp(4);
         // the wave's weight fragments (40 KB for all four waves, L2 / L1 resident): requested here, they
         // arrive while the workgroup gathers at the barrier -- held across the transforms they would
@@ -376,6 +465,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(
             }
         }
         stamp(6);
+        if (wide_ok & 4) {               // (debug: the next group's samples staged with nothing else in flight)
+            __syncthreads();
+            if (grp + stride < total_groups) stage(grp + stride, half ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
 }
 
@@ -392,9 +486,9 @@ hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int bat
     const int total = groups_per_row * batch;
     static LdsLimit limit[2];
     const void* kernel = spec ? reinterpret_cast<const void*>(frontend_kernel<true>) : reinterpret_cast<const void*>(frontend_kernel<false>);
-    const hipError_t e = limit[spec != nullptr].ensure(kernel, LDS_BYTES);
+    const hipError_t e = limit[spec != nullptr].ensure(kernel, 163840);
     if (e != hipSuccess) return e;
-    static int slots = 0;                // resident workgroups (two per CU; the devices of a node are alike)
+    static int slots = 0;                // resident teams: two per workgroup, one workgroup per CU (the devices of a node are alike)
     if (slots == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -402,16 +496,22 @@ hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int bat
             cus = 256;
         slots = 2 * cus;
     }
-    // persistent grid: every workgroup gets the same number of groups, +-1
+    // persistent grid: every team gets the same number of groups, +-1
     const int rounds = (total + slots - 1) / slots;
-    const int grid = (total + rounds - 1) / rounds;
+    const int teams = (total + rounds - 1) / rounds;
+    const int grid = (teams + 1) / 2;
     // 16-byte DMA pieces need 16-byte aligned rows
-    const int wide_ok = (reinterpret_cast<uintptr_t>(audio) % 16 == 0 && samples % 4 == 0) ? 1 : 0;
+    int wide_ok = (reinterpret_cast<uintptr_t>(audio) % 16 == 0 && samples % 4 == 0) ? 1 : 0;
+    size_t lds_bytes = 2 * LDS_BYTES;
+    static const int fe_debug = getenv("PPGS_AMD_FE_DEBUG") ? atoi(getenv("PPGS_AMD_FE_DEBUG")) : 0;   // 1: narrow DMA only, 4: serial staging
+    if (fe_debug & 1) wide_ok = 0;
+    if (fe_debug & 4) wide_ok |= 4;
+    if (fe_debug & 8) lds_bytes = 163840;          // the workgroup has its CU's LDS to itself
     if (spec)
-        hipLaunchKernelGGL(frontend_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, s, tb, audio, samples, frames,
+        hipLaunchKernelGGL(frontend_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, tb, audio, samples, frames,
                            groups_per_row, total, wide_ok, reinterpret_cast<__half*>(spec), reinterpret_cast<__half*>(mel));
     else
-        hipLaunchKernelGGL(frontend_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, s, tb, audio, samples, frames,
+        hipLaunchKernelGGL(frontend_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, tb, audio, samples, frames,
                            groups_per_row, total, wide_ok, reinterpret_cast<__half*>(spec), reinterpret_cast<__half*>(mel));
     return hipGetLastError();
 }

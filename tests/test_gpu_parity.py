@@ -906,6 +906,37 @@ def test_graphed_encode_helper():
         assert (out - ref).abs().max() == 0
 
 
+def test_frontend_and_steps_beside_the_encoder_on_other_streams():
+    """Callers on several HIP streams (the file pipeline runs batch i + 1's frontend beside batch i's encoder): every
+    result equals the one-stream result.  Round 2's frontend (256-thread workgroups that shared a CU with the
+    attention kernel's) got a frame pair wrong about once per 300 pairs in exactly this situation."""
+    engine, state = eng(precision='bf16')
+    gen = torch.Generator().manual_seed(1234)
+    audio = (0.1 * torch.randn(32, 1, 160000, generator=gen)).cuda()
+    lengths = [1000] * 32
+    spec_ref, mel_ref = E.frontend(audio, spectrogram=True, mel=True)
+    ref = engine.encode(mel_ref, lengths)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(12):
+        with torch.cuda.stream(a):
+            for _ in range(2):
+                engine.encode(mel_ref, lengths)
+        with torch.cuda.stream(b):
+            outs = [E.frontend(audio, spectrogram=(rep % 2 == 0), mel=True) for _ in range(4)]
+        torch.cuda.synchronize()
+        for spec, mel in outs:
+            assert torch.equal(mel, mel_ref)
+            assert spec is None or torch.equal(spec, spec_ref)
+    for rep in range(4):
+        outs = []
+        for i in range(16):
+            with torch.cuda.stream((a, b)[i % 2]):
+                outs.append(engine.encode(ppgs_amd.preprocess.mel.from_audios(audio), lengths))
+        torch.cuda.synchronize()
+        assert all(torch.equal(out, ref) for out in outs)
+
+
 def test_graph_capture_spans_both_pipelines():
     """A batch that runs as two pipelines, captured: the fork to the engine's second stream and the join are
     part of the HIP graph, and a replay equals the eager call."""
