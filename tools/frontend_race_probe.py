@@ -19,6 +19,19 @@ torch.cuda.synchronize()
 a, b = torch.cuda.Stream(), torch.cuda.Stream()
 other = sys.argv[1] if len(sys.argv) > 1 else 'encode'
 big = torch.randn(8192, 8192, device='cuda', dtype=torch.bfloat16)
+if other in ('body', 'features'):
+    import transformers
+    transformers.utils.logging.set_verbosity_error()
+    torch.manual_seed(5)
+    hf = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(num_hidden_layers=4)).eval().cuda()
+    if other == 'body':
+        body = E.W2v2Body(hf, 0, 'bf16')
+        body_in = torch.randn(16, 499, 512, device='cuda')
+    else:
+        feats_model = E.W2v2FeatureEncoder(hf.state_dict(), 0, 'bf16')
+        audio16 = audio[:16].contiguous()
+if other == 'sdpa':
+    q_ = torch.randn(32, 2, 1000, 128, device='cuda', dtype=torch.bfloat16)
 total = bad = 0
 for rep in range(40):
     with torch.cuda.stream(a):
@@ -28,6 +41,15 @@ for rep in range(40):
         elif other == 'gemm':
             for _ in range(4):
                 big @ big
+        elif other == 'body':
+            for _ in range(2):
+                body(body_in, [499] * 16)
+        elif other == 'features':
+            for _ in range(2):
+                feats_model(audio16)
+        elif other == 'sdpa':
+            for _ in range(6):
+                torch.nn.functional.scaled_dot_product_attention(q_, q_, q_)
         elif other == 'frontend':
             for _ in range(4):
                 ppgs_amd.preprocess.mel.from_audios(audio)
