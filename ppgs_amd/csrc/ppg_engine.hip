@@ -2290,8 +2290,8 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
     if (on) (void)hipEventRecord(ev.b, s);
     if (f->tb.dbg && getenv("PPGS_AMD_FE_CHECK")) {
         unsigned long long h[64];
-        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, f->tb.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && (h[0] || h[1] || h[2] || h[4] || getenv("PPGS_AMD_FE_CHECK_VERBOSE"))) {
-            fprintf(stderr, "frontend check: %llu transforms checked, %llu dwords of a repeated transform differ from the first\n", h[3], h[4]);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, f->tb.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && (h[0] || h[1] || h[2] || h[4] || h[5] || h[6] || h[7] || getenv("PPGS_AMD_FE_CHECK_VERBOSE"))) {
+            fprintf(stderr, "frontend check: %llu transforms checked, %llu dwords of a repeated transform differ from the first; split stage: %llu / %llu re-reads of Z[k] / Z[N-k] differ, %llu recomputed magnitudes differ\n", h[3], h[4], h[5], h[6], h[7]);
             fprintf(stderr, "frontend check: %llu twiddle reads and %llu sample reads from LDS differ from memory, %llu pass-3 inputs differ from the writers' registers\n", h[0], h[1], h[2]);
             for (int n = 0; n < 6 && n < (int)h[2]; ++n)
                 fprintf(stderr, "   pass-3 input (m, jj, lane, pair) %llu: got %08llx %08llx want %08llx %08llx (workgroup*1000+round %llu)\n", h[32 + 4 * n], h[33 + 4 * n] >> 32, h[33 + 4 * n] & 0xffffffffull,
