@@ -697,6 +697,43 @@ def test_files_to_files_roundtrip(tmp_path):
         assert (torch.load(a) - torch.load(b)).abs().max() < 1e-5
 
 
+def test_file_pipeline_overlapped_batches_equal_one_batch_at_a_time(tmp_path):
+    """from_files_to_files overlaps batch i + 1's H2D copy and frontend with batch i's encoder (two HIP streams) and
+    batch i - 1's writes: every file's posteriors equal, bit for bit, those of the same batches run one at a time with
+    a synchronize in between."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(5)
+    path = tmp_path / 'seeded.pt'
+    torch.save(W.seeded_state_dict(seed=1234), path)
+    files, outs = [], []
+    for i in range(200):
+        samples = int(16000 * rng.uniform(3.0, 9.0))
+        f = tmp_path / f'{i:03d}.wav'
+        wavfile.write(f, 16000, (0.1 * rng.standard_normal(samples)).astype(np.float32))
+        files.append(str(f))
+        outs.append(str(tmp_path / f'{i:03d}.pt'))
+    old = ppgs_amd.core.PRECISION
+    ppgs_amd.core.PRECISION = 'bf16'
+    try:
+        ppgs_amd.from_files_to_files(files, outs, checkpoint=str(path), num_workers=8, gpu=0, max_frames=32000)
+        torch.cuda.synchronize()
+        model = ppgs_amd.core.engine_for('mel', str(path), 0)
+        checked = 0
+        for audios, lengths, names in ppgs_amd.core.loader(files, num_workers=4, max_frames=32000, gpu=0):
+            mel = ppgs_amd.preprocess.mel.from_audios(audios.cuda())
+            frames = (lengths // 160).tolist()
+            ref = model.encode(mel, frames)
+            torch.cuda.synchronize()
+            for row, name in enumerate(names):
+                got = torch.load(outs[files.index(name)])
+                assert got.shape == (40, frames[row])
+                assert torch.equal(got, ref[row, :, :frames[row]].cpu()), name
+                checked += 1
+        assert checked == len(files)
+    finally:
+        ppgs_amd.core.PRECISION = old
+
+
 # ----------------------------------------- configs C4 / C5 as parity cases ---
 
 def test_c4_bucketed_ragged_utterances_vs_oracle():
