@@ -34,12 +34,14 @@ with ``--warmup 5`` times that ramp.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the
 layer kernel): algorithmic FLOPs per launch / its mean launch duration
-measured with HIP events on the launch stream inside the timed region.
+measured with HIP events on the launch stream inside the timed region, priced
+against the WHOLE chip's dense MFMA peak (`roofline.frac`).
 The engine runs a batch of this size as TWO pipelines (half-batches on two HIP
-streams; the same bits at this batch): a layer launch is then 128 one-per-CU workgroups,
-its ceiling is the MFMA peak of the 128 CUs it can occupy (`roofline.peak`,
-`peak_scope`; `frac_of_whole_chip` beside it), and `alt_single_pipeline` is the
-same step with PPGS_AMD_STREAMS=1, where a launch has the whole chip.
+streams; the same bits at this batch): a layer launch is then 128 one-per-CU workgroups
+beside the other pipeline's kernels, so one launch can reach at most half the chip's
+peak (`frac_of_occupied_cus` prices it against the CUs it occupies); the step as a
+whole is `end_to_end_mfma_frac`, and `alt_single_pipeline` is the same step with
+PPGS_AMD_STREAMS=1, where a launch has the whole chip to itself.
 `cpu_baseline` is the CPU oracle (fp32 restatement of the reference path,
 proven equal to the reference modules by tests/test_oracle_golden.py) timed on
 the host cores on the same 32 x 1000 batch, plus its bf16-autocast variant
@@ -152,31 +154,59 @@ def cpu_baseline(state, seconds):
     }
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of the dominant kernel from the newest
-    committed rocprofv3 PMC summary (profiles/r*_pmc_summary.txt; separate
-    --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 reports half of
-    a wide coalesced read, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB.
-    PMC counters cannot be read inside this process, so the figure is NOT of the run that prints it: the
-    record names the file it was read from (`traffic_from`); null when no summary names the kernel."""
+def pmc_summary():
+    """The committed rocprofv3 PMC summary of THIS build: profiles/r*_pmc_summary.txt whose `# lib_sha256_16=` header
+    equals the sha256 of the library this process loaded (tests/pmc_summary.py writes it; a clean `make` reproduces
+    the library byte for byte).  PMC counters cannot be read inside this process, so the figures are never of the
+    run that prints them -- and a summary of another build is not quoted at all.
+    -> ({kernel: {counter: mean per dispatch, 'dispatches': n}}, file) or (None, reason)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.txt')))
-    if not files:
-        return None, None
-    fetch = write = None
-    lines = [line for line in open(files[-1]) if line.startswith(kernel)]
-    # several variants of the kernel in one run: the one with the Q/K/V tail
-    # (4 of the 5 launches of a step) is the one the roofline line describes
-    tail = [line for line in lines if re.search(r', true\b|Lb1', line.split(':')[0])]
-    for line in tail or lines:
-        m = re.search(r'FETCH_SIZE=([0-9.e+]+)', line)
-        fetch = float(m.group(1)) if m else fetch
-        m = re.search(r'WRITE_SIZE=([0-9.e+]+)', line)
-        write = float(m.group(1)) if m else write
-    if fetch is None or write is None:
-        return None, None
-    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
+    from tests.pmc_summary import library_sha16
+    from ppgs_amd import engine as E
+    sha = library_sha16(E._LIB_PATH)
+    seen = []
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.txt')), reverse=True):
+        with open(path) as f:
+            text = f.read()
+        m = re.search(r'^# lib_sha256_16=([0-9a-f]+)', text, re.M)
+        seen.append(f'{os.path.basename(path)}:{m.group(1) if m else "unlabelled"}')
+        if not m or m.group(1) != sha:
+            continue
+        kernels = {}
+        for line in text.splitlines():
+            if line.startswith(('#', '==')) or ': ' not in line:
+                continue
+            name, rest = line.split(': ', 1)
+            entry = kernels.setdefault(name, {})
+            for key, value in re.findall(r'(\w+)=([0-9.e+-]+)', rest):
+                entry[key] = max(entry.get(key, 0.0), float(value)) if key == 'dispatches' else float(value)
+        return kernels, os.path.relpath(path, ROOT)
+    return None, f'no committed PMC summary of this build (library {sha}; committed: {", ".join(seen) or "none"})'
+
+
+def pmc_traffic(kernels, prefix):
+    """HBM-side bytes per launch of the dominant kernel: 2 x FETCH_SIZE (gfx950 reports half of a wide coalesced
+    read, MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB; the variant with the Q/K/V tail (4 of the 5 launches of a
+    step) is the one the roofline line describes."""
+    import re
+    names = [k for k in kernels if k.startswith(prefix)]
+    tail = [k for k in names if re.search(r', true\b|Lb1', k)]
+    for name in tail or names:
+        entry = kernels[name]
+        if 'FETCH_SIZE' in entry and 'WRITE_SIZE' in entry:
+            return (2.0 * entry['FETCH_SIZE'] + entry['WRITE_SIZE']) * 1024.0
+    return None
+
+
+def pmc_mfma_busy(kernels):
+    """Matrix-pipe busy cycles of ONE step, all kernels: sum of SQ_VALU_MFMA_BUSY_CYCLES per dispatch x dispatches per
+    step (dispatches relative to the frontend's, which runs once per step)."""
+    front = [k for k in kernels if 'FrontendTables' in k or k.startswith('frontend_kernel')]
+    if not front or not kernels[front[0]].get('dispatches'):
+        return None
+    steps = kernels[front[0]]['dispatches']
+    return sum(e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) * e.get('dispatches', 0.0) / steps for e in kernels.values())
 
 
 ###############################################################################
@@ -365,7 +395,9 @@ def run_c2(args, rank, world, local_rank, use_dist):
     launch_cus = min(launch_workgroups, cus) if launch_workgroups else cus
     launch_peak = peak * launch_cus / cus
     layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
-    traffic, traffic_from = pmc_traffic('layer32_' if layer32 else 'ffn_')
+    pmc, pmc_from = pmc_summary()
+    traffic = pmc_traffic(pmc, 'layer32_' if layer32 else 'ffn_') if pmc else None
+    mfma_busy = pmc_mfma_busy(pmc) if pmc else None
     kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
                    'W1+ReLU+W2+residual+LN2' + (', next layer Q/K/V)' if qkv_fused_layers else ')')) if layer32 else (
         'ffn_mixed_kernel (token-split layer kernel: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
@@ -398,23 +430,34 @@ def run_c2(args, rank, world, local_rank, use_dist):
             'kernel': kernel_name,
             'bound': 'mfma',
             'achieved': ffn_tflops,
-            'peak': launch_peak,
+            'peak': peak,
             'unit': 'TFLOP/s',
-            'frac': ffn_tflops / launch_peak,
-            'peak_scope': f'{launch_cus} of {cus} CUs: a launch is {launch_workgroups or "?"} workgroups, one per CU '
-                          f'({pipelines} pipeline(s) of the batch run beside each other); whole-chip dense peak {peak}',
-            'frac_of_whole_chip': ffn_tflops / peak,
+            'frac': ffn_tflops / peak,
+            'peak_scope': f'whole chip ({cus} CUs, dense {args.precision} MFMA peak of MI355X_MICROARCH.md).  A launch is '
+                          f'{launch_workgroups or "?"} workgroups, one per CU, and {pipelines} pipeline(s) of the batch run '
+                          'beside each other: `achieved` is ONE launch\'s FLOPs over its own duration while the other '
+                          'pipeline\'s kernels share the chip -- the step as a whole is end_to_end_mfma_frac, and '
+                          'alt_single_pipeline has the per-launch figure with the chip to itself',
+            'frac_of_occupied_cus': ffn_tflops / launch_peak,
+            'occupied_cus': launch_cus,
             'pipelines': pipelines,
             'traffic': traffic,
-            'traffic_from': traffic_from and f'{traffic_from} (committed rocprofv3 --pmc passes of this command, '
-                                             'not this run)',
+            'traffic_from': f'{pmc_from} (committed rocprofv3 --pmc passes of this command and this build, not this run)'
+                            if pmc else pmc_from,
             'flops_per_launch': ffn_flops,
             'mean_launch_ms': ffn_ms / max(ffn_samples, 1),
             'timed_launches': ffn_samples,
         },
         'end_to_end_tflops': step_flops * args.steps / elapsed / 1e12,
         'end_to_end_mfma_frac': step_flops * args.steps / elapsed / 1e12 / peak,
-        'kernel_ms_per_step': {k: v[0] / breakdown_steps for k, v in kernels.items()},
+        # HIP-event durations summed over BOTH pipelines' streams: with two pipelines the classes overlap in time and
+        # the sum exceeds the step (divide a class by `pipelines` for its share of the wall clock, roughly)
+        'kernel_ms_per_step_stream_summed': {k: v[0] / breakdown_steps for k, v in kernels.items()},
+        'kernel_ms_pipelines': pipelines,
+        # matrix-pipe busy cycles of a step (all kernels, rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass
+        # of this build) over 4 pipes x CUs x the step's duration at the nominal 2.4 GHz the 2.5 PF peak is quoted at
+        'mfma_busy_cycles_per_step': mfma_busy,
+        'mfma_busy_frac': mfma_busy / (4.0 * cus * ms_per_step * 2.4e6) if mfma_busy else None,
         'repeat_blocks_ms_per_step': repeats,
         'h2d_ms': copies['h2d_ms'],
         'd2h_ms': copies['d2h_ms'],
@@ -514,9 +557,13 @@ def run_c4(args, rank, world, local_rank, use_dist):
         processed += info.processed_frames
         chip_share += info.processed_frames / model.pipelines(info.tokens)
     per_frame = 4.0 * HIDDEN * FFN + 2.0 * HIDDEN * HIDDEN + 6.0 * HIDDEN * HIDDEN * (LAYERS - 1) / LAYERS
-    # launch durations are summed over both pipelines of a split batch: weight them by the share of the chip a launch holds
+    # plain whole-chip accounting: the layer FLOPs of the pass over the SUM of the layer launches' durations (HIP events,
+    # both pipelines' streams), every launch priced against the whole chip -- a launch of a two-pipeline batch shares
+    # the chip with the other pipeline's kernels, so this is a lower bound; the chip-share weighting (a launch of a
+    # p-pipeline batch holds 1/p of the CUs) is kept beside it as frac_of_occupied_cus
+    ffn_tflops = per_frame * processed * LAYERS * args.steps / (1e-3 * ffn_ms) / 1e12 if ffn_ms else 0.0
     chip_ms = ffn_ms * chip_share / max(processed, 1)
-    ffn_tflops = per_frame * processed * LAYERS * args.steps / (1e-3 * chip_ms) / 1e12 if ffn_ms else 0.0
+    occupied_tflops = per_frame * processed * LAYERS * args.steps / (1e-3 * chip_ms) / 1e12 if ffn_ms else 0.0
     peak = PEAK_FP32_TFLOPS if args.precision == 'fp32' else PEAK_16BIT_TFLOPS
     padded_frames = sum(len(b) * max(frames[mine[j]] for j in b) for b in batches)
     return {
@@ -547,8 +594,10 @@ def run_c4(args, rank, world, local_rank, use_dist):
             'kernel': 'layer kernel launches of rank 0 (layer32_kernel / token-split kernels by batch size)',
             'bound': 'mfma', 'achieved': ffn_tflops, 'peak': peak, 'unit': 'TFLOP/s',
             'frac': ffn_tflops / peak, 'traffic': None,
+            'frac_of_occupied_cus': occupied_tflops / peak,
             'mean_launch_ms': ffn_ms / max(ffn_launches, 1), 'timed_launches': ffn_launches,
             'chip_share_of_a_launch': chip_share / max(processed, 1),
+            'end_to_end_mfma_frac': sum(data.flops(f) for f in frames) * args.steps / elapsed / 1e12 / peak,
         },
     }
 

@@ -282,8 +282,12 @@ def from_dataloader(dataloader, output_files,
         host, filenames, frame_lengths, keep = slot.job
         slot.done.synchronize()
         slot.job = None
-        # (the batch is complete on the device: a non-finite logit in it has set the engine's flag by now)
-        if engine_for(representation, checkpoint, device.index).nonfinite(clear=True):
+        # The check is on THIS batch's own posteriors (pinned host memory, complete): the engine's sticky flag is
+        # engine-wide, and the other slot's batch is already in flight on the same engine -- its NaN would be
+        # charged to this batch and cleared before its own retirement.  The flag is cleared here only so that
+        # from_file_to_file / check_finite callers after the job do not inherit it.
+        if not bool(torch.isfinite(host).all()):
+            engine_for(representation, checkpoint, device.index).nonfinite(clear=True)
             warnings.warn(
                 f'Skipping a batch of {len(filenames)} files ({filenames[0]} ...): non-finite posteriors '
                 f'({PRECISION} operands out of range, or non-finite audio); PPGS_AMD_PRECISION=bf16 / fp32 '
@@ -350,17 +354,6 @@ def infer(features, lengths, representation='mel', checkpoint=None,
     return out
 
 
-_side_streams = {}
-
-
-def _side_stream(device):
-    """One extra HIP stream per device for host-tensor conversions (file loading in a background
-    thread must not queue behind -- or in front of -- the pipelines' kernels on the default stream)."""
-    if device.index not in _side_streams:
-        _side_streams[device.index] = torch.cuda.Stream(device)
-    return _side_streams[device.index]
-
-
 def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE, gpu=None):
     """Perform audio resampling (reference ppgs/core.py:599-608; `gpu` is this package's
     addition: which HIP device converts a HOST tensor -- default the current one).
@@ -371,7 +364,7 @@ def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE, gpu=None):
     implementation in this package (torchaudio is absent in the build image:
     the kernel follows its published algorithm and is tested against a fixture
     computed from the closed-form filter in float64, tests/golden/g10).  Host
-    tensors (file loading) make the round trip through the current HIP device
+    tensors (file loading) make the round trip through HIP device `gpu`
     and come back on the host, like every other entry point of an engine
     without a CPU path.
     """
@@ -379,7 +372,7 @@ def resample(audio, sample_rate, target_rate=config.SAMPLE_RATE, gpu=None):
         return audio
     if audio.is_cuda:
         return engine.resample(audio, sample_rate, target_rate)
-    device = device_for(None)
+    device = device_for(gpu)
     return engine.resample(audio.to(device), sample_rate, target_rate).cpu()
 
 

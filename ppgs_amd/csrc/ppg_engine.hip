@@ -1501,7 +1501,9 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     // partial sums of the split-hidden FFN launches: [splits][batch * R][H] fp32, at most 256 MiB
     {
         const int chunks = c.ffn_channels / (32768 / (c.hidden_channels * e->sz));
-        const size_t per_split = (size_t)MT * c.hidden_channels * 4;
+        // (under a row map a split's rows are slot-dense, ceil(map_blocks / 4) * 64 of them -- ppg_kernels.hip, ffn_body's
+        // epilogue and the reduce pass: up to MT rounded up to a whole 64-row workgroup, not MT)
+        const size_t per_split = (size_t)round_up(MT, 64) * c.hidden_channels * 4;
         st->max_splits = 1;
         while (st->max_splits * 2 <= std::max(1, chunks / 2) && (size_t)(st->max_splits * 2) * per_split <= ((size_t)256 << 20)) st->max_splits *= 2;
         st->part_off = align_up(st->ws.total, 256);
@@ -1600,30 +1602,34 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
     maps.assign(3 * (size_t)tb.max_blocks, 0);
     int nmap[3] = {0, 0, 0}, nitems = 0, max_count = 0;
     const int tile = e->head_dim == 128 ? ppg::attn_query_tile(e->head_dim) / 2 : ppg::attn_query_tile(e->head_dim);
+    // the items' new frontiers are worked out on copies and committed only once every launch of the step is queued:
+    // a step that fails half way (too many query tiles, a refused launch) leaves the stream where it was
+    std::vector<int> received = st->received, x_valid = st->x_valid, o_valid = st->o_valid;
+    std::vector<char> finished = st->finished;
     for (int b = 0; b < B; ++b) {
         const int n = counts[b];
         const bool fl = flush && flush[b];
         const bool active = n > 0 || fl;
-        const int f_prev = st->received[b], x_prev = st->x_valid[b], o_prev = st->o_valid[b];
-        if (active) st->received[b] += n;
-        const int x_new = !active ? x_prev : (fl ? st->received[b] : std::max(st->received[b] - 2, 0));
-        const int o_new = !active ? o_prev : (fl ? st->received[b] : std::max(x_new - 2, 0));
+        const int f_prev = received[b], x_prev = x_valid[b], o_prev = o_valid[b];
+        if (active) received[b] += n;
+        const int x_new = !active ? x_prev : (fl ? received[b] : std::max(received[b] - 2, 0));
+        const int o_new = !active ? o_prev : (fl ? received[b] : std::max(x_new - 2, 0));
         if (first_final) first_final[b] = o_prev;
         if (num_final) num_final[b] = o_new - o_prev;
-        if (fl) st->finished[b] = 1;
-        st->x_valid[b] = x_new; st->o_valid[b] = o_new;
+        if (fl) finished[b] = 1;
+        x_valid[b] = x_new; o_valid[b] = o_new;
         // the item's window as the three kinds of launch see it
         PpgWindow w{};
         w.item = b; w.chunked = 0; w.start = 0; w.frames = R; w.valid = x_new;
         w.keep_lo = 0; w.keep_hi = R; w.out_frame = 0; w.vt_off = b * R; w.tok_off = b * R;
         win[b] = w;
-        win[B + b] = w; win[B + b].frames = fl ? st->received[b] : R;    // out-conv: zero padding at the true end once it is known
+        win[B + b] = w; win[B + b].frames = fl ? received[b] : R;    // out-conv: zero padding at the true end once it is known
         win[2 * B + b] = w;
         meta[b] = StreamItemMeta{b * R, f_prev, active ? n : 0, 0};
         max_count = std::max(max_count, meta[b].count);
         if (!active) continue;
         const int r0 = x_prev / 16 * 16, r1 = round_up(x_new, 16);          // rows of the residual stream to (re)compute
-        const int g0 = f_prev / 16 * 16, g1 = round_up(st->received[b], 16);  // rows whose features changed
+        const int g0 = f_prev / 16 * 16, g1 = round_up(received[b], 16);  // rows whose features changed
         const int o0 = o_prev / 16 * 16, o1 = round_up(o_new, 16);          // posterior rows
         for (int r = r0; r < r1; r += 16) maps[nmap[0]++] = b * R + r;
         for (int r = o0; r < o1; r += 16) maps[tb.max_blocks + nmap[1]++] = b * R + r;
@@ -1757,6 +1763,7 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
     }
 #undef LAUNCH_OK
     HIP_OK(hipEventRecord(st->uploaded[slot_index], s));
+    st->received.swap(received); st->x_valid.swap(x_valid); st->o_valid.swap(o_valid); st->finished.swap(finished);
     return PPG_OK;
 }
 

@@ -59,7 +59,20 @@ constexpr int OFF_SEG = OFF_TW + 64 * 8;                    // float[2][SEGP]
 constexpr int OFF_FFT = OFF_SEG + 2 * SEGP * 4;             // float2[4][BUF]
 constexpr int OFF_MAG = OFF_FFT + 4 * BUF * 8;              // fp16 rows [16][MROW / 2]
 constexpr int LDS_BYTES = OFF_MAG + FPB * MROW;
-static_assert(2 * LDS_BYTES <= 163840 && LDS_BYTES % 16 == 0, "two teams per workgroup, the workgroup = the CU's LDS");
+// Four-wave teams per workgroup.  The product is 2: a 512-thread workgroup that requests the CU's whole LDS, so no other
+// kernel's workgroup can sit beside it.  -DPPG_FE_R2 rebuilds round 2's launch -- one team, 256 threads,
+// 79.5 KiB, two workgroups per CU or one beside another kernel's -- as the REPRODUCER of the co-residency failure for
+// tools/frontend_race_probe.py / tools/coresidency_matrix.py; it is never the product.
+#ifdef PPG_FE_R2
+constexpr int TEAMS = 1;
+#else
+constexpr int TEAMS = 2;
+#endif
+#ifndef PPG_FE_MIN_BLOCKS
+#define PPG_FE_MIN_BLOCKS (2 / TEAMS)
+#endif
+constexpr int CU_LDS_BYTES = 163840;
+static_assert(2 * LDS_BYTES <= CU_LDS_BYTES && LDS_BYTES % 16 == 0, "two teams per CU; a two-team workgroup = the CU's LDS");
 static_assert(OFF_MAG % 16 == 0 && MROW % 16 == 0, "fragment reads are 16-byte aligned");
 
 // Complex arithmetic on (re, im) register pairs with the packed fp32 instructions.  Swapping or negating
@@ -162,13 +175,16 @@ __device__ __forceinline__ void wave_sync() {
 // complex arithmetic change nothing, a CU of its own gives 0 of 240 launches wrong against 160).  The two teams
 // share nothing but the barriers.
 template <bool SPEC>
-__global__ __launch_bounds__(512, 1) void frontend_kernel(
+__global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kernel(
     ppg::FrontendTables tb, const float* __restrict__ audio, int samples, int frames,
     int groups_per_row, int total_groups, int wide_ok, __half* __restrict__ spec, __half* __restrict__ mel)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
-    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int team = TEAMS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     char* smem = smem_all + team * LDS_BYTES;
+#ifdef PPG_FE_SETPRIO
+    __builtin_amdgcn_s_setprio(PPG_FE_SETPRIO);
+#endif
     cplx* tw = reinterpret_cast<cplx*>(smem + OFF_TW);
     float* seg0 = reinterpret_cast<float*>(smem + OFF_SEG);
 
@@ -235,8 +251,8 @@ __global__ __launch_bounds__(512, 1) void frontend_kernel(
                          :: "v"(p), "s"(__builtin_amdgcn_readfirstlane(dst + piece * 256)) : "memory", "m0");
         }
     };
-    const int stride = 2 * gridDim.x;
-    const int first_group = 2 * blockIdx.x + team;
+    const int stride = TEAMS * gridDim.x;
+    const int first_group = TEAMS * blockIdx.x + team;
     if (first_group < total_groups) stage(first_group, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void frontend_kernel(
     int half = 0;
     // (both teams make the same number of trips -- the barriers are the workgroup's; a team past its last group
     // runs an empty trip: every frame of it lies past the row's end, nothing is transformed or stored)
-    const int trips = (total_groups - 2 * (int)blockIdx.x + stride - 1) / stride;
+    const int trips = (total_groups - TEAMS * (int)blockIdx.x + stride - 1) / stride;
     int grp = first_group;
     for (int trip = 0; trip < trips; ++trip, grp += stride, half ^= 1) {
         const bool active = grp < total_groups;
@@ -486,7 +502,7 @@ hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int bat
     const int total = groups_per_row * batch;
     static LdsLimit limit[2];
     const void* kernel = spec ? reinterpret_cast<const void*>(frontend_kernel<true>) : reinterpret_cast<const void*>(frontend_kernel<false>);
-    const hipError_t e = limit[spec != nullptr].ensure(kernel, 163840);
+    const hipError_t e = limit[spec != nullptr].ensure(kernel, CU_LDS_BYTES);
     if (e != hipSuccess) return e;
     static int slots = 0;                // resident teams: two per workgroup, one workgroup per CU (the devices of a node are alike)
     if (slots == 0) {
@@ -499,19 +515,22 @@ hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int bat
     // persistent grid: every team gets the same number of groups, +-1
     const int rounds = (total + slots - 1) / slots;
     const int teams = (total + rounds - 1) / rounds;
-    const int grid = (teams + 1) / 2;
+    const int grid = (teams + TEAMS - 1) / TEAMS;
     // 16-byte DMA pieces need 16-byte aligned rows
     int wide_ok = (reinterpret_cast<uintptr_t>(audio) % 16 == 0 && samples % 4 == 0) ? 1 : 0;
-    size_t lds_bytes = 2 * LDS_BYTES;
+    // the product workgroup asks for ALL of the CU's LDS (not just its two teams' 2 x 79.5 KiB): a kernel that needs
+    // <= 1 KiB of LDS would otherwise still fit beside it
+    size_t lds_bytes = TEAMS == 2 ? CU_LDS_BYTES : LDS_BYTES;
     static const int fe_debug = getenv("PPGS_AMD_FE_DEBUG") ? atoi(getenv("PPGS_AMD_FE_DEBUG")) : 0;   // 1: narrow DMA only, 4: serial staging
     if (fe_debug & 1) wide_ok = 0;
     if (fe_debug & 4) wide_ok |= 4;
-    if (fe_debug & 8) lds_bytes = 163840;          // the workgroup has its CU's LDS to itself
+    if (fe_debug & 8) lds_bytes = CU_LDS_BYTES;    // (repro variant: the one-team workgroup alone on its CU)
+    if (fe_debug & 16) lds_bytes = TEAMS * LDS_BYTES;   // (product variant with the exact request: small-LDS kernels may co-reside)
     if (spec)
-        hipLaunchKernelGGL(frontend_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, tb, audio, samples, frames,
+        hipLaunchKernelGGL(frontend_kernel<true>, dim3(grid), dim3(256 * TEAMS), lds_bytes, s, tb, audio, samples, frames,
                            groups_per_row, total, wide_ok, reinterpret_cast<__half*>(spec), reinterpret_cast<__half*>(mel));
     else
-        hipLaunchKernelGGL(frontend_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, tb, audio, samples, frames,
+        hipLaunchKernelGGL(frontend_kernel<false>, dim3(grid), dim3(256 * TEAMS), lds_bytes, s, tb, audio, samples, frames,
                            groups_per_row, total, wide_ok, reinterpret_cast<__half*>(spec), reinterpret_cast<__half*>(mel));
     return hipGetLastError();
 }

@@ -1364,6 +1364,38 @@ def test_batched_kv_cached_streams_equal_causal_forward(precision):
         stream.push(torch.zeros(batch, 80, 4).cuda(), [4] * batch)        # every item was flushed
 
 
+@pytest.mark.parametrize('batch', [1, 3])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_stream_near_full_push_after_small_push(precision, batch):
+    """with batch * rows % 64 == 32 (capacity 150 -> 160 rows, odd batch) a step that touches nearly
+    all 16-row blocks gives the split-hidden FFN a partial-row stride of ceil(blocks / 4) * 64 > batch * rows; the
+    partial buffer was sized for batch * rows and the last splits wrote into the K | Q / V^T caches of the layers
+    behind it -- cached rows the step does not recompute.  A small push (rows 0..15 cached), then a near-full one."""
+    engine, state = eng(precision=precision, causal=True)
+    gen = torch.Generator().manual_seed(150)
+    totals = [150, 150, 139][:batch]
+    feats = [torch.randn(80, n, generator=gen).half() for n in totals]
+    ref = [O.from_features(state, f[None].float(), torch.tensor([n]), is_causal=True).numpy()[0] for f, n in zip(feats, totals)]
+    stream = engine.batched_stream(batch, 150)
+    assert stream.rows == 160
+    pieces = [[] for _ in range(batch)]
+    sent = [0] * batch
+    for size in (20, 130):
+        counts = [min(size, totals[b] - sent[b]) for b in range(batch)]
+        chunk = torch.zeros(batch, 80, max(counts), dtype=torch.float16)
+        for b in range(batch):
+            chunk[b, :, :counts[b]] = feats[b][:, sent[b]:sent[b] + counts[b]]
+        out = stream.push(chunk.cuda(), counts, flush=(size == 130))
+        for b in range(batch):
+            sent[b] += counts[b]
+            pieces[b].append(out[b])
+    tol = FP32_TOL if precision == 'fp32' else 2e-3
+    for b in range(batch):
+        got = torch.cat(pieces[b], dim=1).cpu().numpy()
+        assert got.shape == (40, totals[b])
+        assert np.abs(got - ref[b]).max() < tol, (b, np.abs(got - ref[b]).max())
+
+
 def test_fp16_overflow_sets_the_sticky_flag():
     """fp16 operands end at 65504.  A checkpoint whose FFN activations pass that (layer 2's linear1 scaled by 3e4)
     turns into NaN posteriors in the fp16 mode: the engine's sticky flag reports it (Engine.nonfinite /

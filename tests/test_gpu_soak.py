@@ -1,0 +1,170 @@
+"""Containment soak: the kernels of this package beside OTHER kernels on the chip.
+
+Round 2's 256-thread mel frontend computed a frame pair wrong about once per 300 pairs when an attention kernel of
+another HIP stream shared its CU (PyTorch's own scaled_dot_product_attention is enough).  Since round 3 the product
+runs kernels of its own two pipelines side by side by default, so every victim below is driven for thousands of
+launches with `torch.nn.functional.scaled_dot_product_attention` hammering a third stream, and every result must be
+bit-identical to the result of the same call on a quiet chip in the one-pipeline configuration:
+
+  * ppg_encode as two pipelines (bf16 and fp16), >= 2000 C2 steps each,
+  * the mel frontend (512-thread workgroups that own their CU),
+  * the wav2vec2 body as two pipelines,
+  * the batched KV-cached stream step (row-mapped launches).
+
+The comparisons run on the device (one flag per step, summed) so that the host never drains the queues: victim and
+aggressor stay co-resident for the whole run.
+"""
+import pytest
+import torch
+
+import ppgs_amd
+from ppgs_amd import engine as E
+from ppgs_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 2000
+
+
+class Aggressor:
+    """scaled_dot_product_attention on a stream of its own, topped up as the victim loop goes."""
+
+    def __init__(self, per_step=3):
+        self.stream = torch.cuda.Stream()
+        self.q = torch.randn(32, 2, 1000, 128, device='cuda', dtype=torch.bfloat16)
+        self.per_step = per_step
+        self.launched = 0
+
+    def top_up(self):
+        with torch.cuda.stream(self.stream):
+            for _ in range(self.per_step):
+                torch.nn.functional.scaled_dot_product_attention(self.q, self.q, self.q)
+        self.launched += self.per_step
+
+
+def soak(step, reference, steps, aggressor, flush_every=250):
+    """`steps` calls of step() on the current stream beside the aggressor; number of results != reference."""
+    bad = torch.zeros((), dtype=torch.int64, device='cuda')
+    for index in range(steps):
+        aggressor.top_up()
+        out = step()
+        bad += (out != reference).any()
+        if index % flush_every == flush_every - 1:
+            torch.cuda.synchronize()           # (bounds the queue depth; both streams are refilled right after)
+    torch.cuda.synchronize()
+    return int(bad)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_soak_encode_two_pipelines_beside_sdpa(monkeypatch, precision):
+    state = W.seeded_state_dict(seed=1234)
+    gen = torch.Generator().manual_seed(77)
+    feats = torch.randn(32, 80, 1000, generator=gen).half().cuda()
+    lengths = [1000] * 32
+    monkeypatch.setenv('PPGS_AMD_STREAMS', '1')
+    reference = E.Engine(state, 0, precision).encode(feats, lengths).clone()
+    monkeypatch.delenv('PPGS_AMD_STREAMS')
+    engine = E.Engine(state, 0, precision)
+    _, info = E.plan_windows(32, 1000, lengths, engine=engine)
+    assert engine.pipelines(info.tokens) == 2
+    torch.cuda.synchronize()
+    aggressor = Aggressor()
+    victim = torch.cuda.Stream()
+    with torch.cuda.stream(victim):
+        bad = soak(lambda: engine.encode(feats, lengths), reference, STEPS, aggressor)
+    assert bad == 0, f'{bad} of {STEPS} two-pipeline {precision} steps beside SDPA differ from the quiet one-pipeline result'
+    assert aggressor.launched >= STEPS
+
+
+def test_soak_frontend_beside_sdpa():
+    gen = torch.Generator().manual_seed(1234)
+    audio = (0.1 * torch.randn(32, 1, 160000, generator=gen)).cuda()
+    reference = ppgs_amd.preprocess.mel.from_audios(audio).clone()
+    torch.cuda.synchronize()
+    aggressor = Aggressor(per_step=1)
+    victim = torch.cuda.Stream()
+    with torch.cuda.stream(victim):
+        bad = soak(lambda: ppgs_amd.preprocess.mel.from_audios(audio), reference, STEPS, aggressor)
+    assert bad == 0, f'{bad} of {STEPS} frontend launches beside SDPA differ'
+
+
+def test_soak_whole_steps_on_two_caller_streams_beside_sdpa():
+    """The file pipeline's shape: whole steps (frontend + two-pipeline encode) alternating on two caller streams, so that
+    one step's frontend runs beside the other's encoder, with the external aggressor on top."""
+    state = W.seeded_state_dict(seed=1234)
+    engine = E.Engine(state, 0, 'bf16')
+    gen = torch.Generator().manual_seed(5)
+    audio = (0.1 * torch.randn(32, 1, 160000, generator=gen)).cuda()
+    lengths = [1000] * 32
+    reference = engine.encode(ppgs_amd.preprocess.mel.from_audios(audio), lengths).clone()
+    torch.cuda.synchronize()
+    aggressor = Aggressor(per_step=2)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # one counter per caller stream, updated on that stream (a flag handed to another stream would race with the
+    # caching allocator reusing its block)
+    bad = [torch.zeros((), dtype=torch.int64, device='cuda') for _ in streams]
+    total = 600
+    for index in range(total):
+        aggressor.top_up()
+        with torch.cuda.stream(streams[index % 2]):
+            out = engine.encode(ppgs_amd.preprocess.mel.from_audios(audio), lengths)
+            bad[index % 2] += (out != reference).any()
+        if index % 100 == 99:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    wrong = int(bad[0]) + int(bad[1])
+    assert wrong == 0, f'{wrong} of {total} overlapped steps differ'
+
+
+def test_soak_w2v2_body_two_pipelines_beside_sdpa(monkeypatch):
+    import transformers
+    transformers.utils.logging.set_verbosity_error()
+    torch.manual_seed(5)
+    hf = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(num_hidden_layers=4)).eval()
+    x = torch.randn(16, 499, 512, generator=torch.Generator().manual_seed(4)).cuda()
+    valid = [499] * 16
+    monkeypatch.setenv('PPGS_AMD_W2V2_STREAMS', '1')
+    reference = E.W2v2Body(hf, 0, 'bf16')(x, valid).clone()
+    monkeypatch.delenv('PPGS_AMD_W2V2_STREAMS')
+    body = E.W2v2Body(hf, 0, 'bf16')
+    torch.cuda.synchronize()
+    aggressor = Aggressor(per_step=4)
+    victim = torch.cuda.Stream()
+    steps = 500
+    with torch.cuda.stream(victim):
+        bad = soak(lambda: body(x, valid), reference, steps, aggressor, flush_every=100)
+    assert bad == 0, f'{bad} of {steps} two-pipeline body forwards beside SDPA differ'
+
+
+def test_soak_batched_stream_steps_beside_sdpa():
+    """64 KV-cached causal streams advanced 16 frames per step: the whole 30-step sequence repeated beside the
+    aggressor equals the quiet run, output by output."""
+    state = W.seeded_state_dict(seed=1234)
+    engine = E.Engine(state, 0, 'bf16', True)
+    gen = torch.Generator().manual_seed(12)
+    batch, frames, hop = 64, 480, 16
+    feats = torch.randn(batch, 80, frames, generator=gen).half().cuda()
+
+    def sequence(aggressor=None):
+        stream = engine.batched_stream(batch, frames)
+        outs = []
+        for step in range(frames // hop):
+            if aggressor is not None:
+                aggressor.top_up()
+            last = step == frames // hop - 1
+            out = stream.push(feats[:, :, step * hop:(step + 1) * hop], flush=last)
+            outs.append(torch.cat([piece for piece in out], dim=1))
+        return outs
+
+    reference = sequence()
+    torch.cuda.synchronize()
+    aggressor = Aggressor(per_step=1)
+    victim = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device='cuda')
+    reps = 70                                        # 70 x 30 = 2100 steps
+    with torch.cuda.stream(victim):
+        for rep in range(reps):
+            for out, ref in zip(sequence(aggressor), reference):
+                bad += (out != ref).any()
+            torch.cuda.synchronize()
+    assert int(bad) == 0, f'{int(bad)} of {reps * (frames // hop)} stream steps beside SDPA differ'
