@@ -597,7 +597,7 @@ def run_c4(args, rank, world, local_rank, use_dist):
             'frac_of_occupied_cus': occupied_tflops / peak,
             'mean_launch_ms': ffn_ms / max(ffn_launches, 1), 'timed_launches': ffn_launches,
             'chip_share_of_a_launch': chip_share / max(processed, 1),
-            'end_to_end_mfma_frac': sum(data.flops(f) for f in frames) * args.steps / elapsed / 1e12 / peak,
+            'end_to_end_mfma_frac': sum(data.flops(f) for f in frames) * args.steps / elapsed / 1e12 / peak / world,
         },
     }
 

@@ -76,9 +76,18 @@ static_assert(2 * LDS_BYTES <= CU_LDS_BYTES && LDS_BYTES % 16 == 0, "two teams p
 static_assert(OFF_MAG % 16 == 0 && MROW % 16 == 0, "fragment reads are 16-byte aligned");
 
 // Complex arithmetic on (re, im) register pairs with the packed fp32 instructions.  Swapping or negating
-// a half of an operand is an instruction modifier (op_sel / neg_lo / neg_hi), which the compiler does not
-// use for v_pk_*_f32: written in C++, every multiplication by -i and every complex product cost two
-// v_mov_b32 to build the swapped pair -- a quarter of the kernel's vector instructions.
+// a half of an operand is an instruction modifier (op_sel / neg_lo / neg_hi): written without them, every
+// multiplication by -i and every complex product costs two v_mov_b32 to build the swapped pair.
+//
+// ONE operand position must never be re-selected: SOURCE 1 with its op_sel bit set (the low result half reading
+// the HIGH half of source 1 -- a swap or a broadcast of the high half).  On gfx950 that form intermittently
+// computes with the wrong half while ANOTHER wave of the same SIMD issues 16x16x32 MFMAs -- a wave of another
+// kernel (round 2's 256-thread workgroups beside an attention kernel: one frame pair in ~300 wrong) or of the same
+// workgroup; source 0, source 2 and every selection with op_sel[1] = 0 are unaffected
+// (tools/probes/pk_mfma_probe.hip reproduces it without this package).  Add and multiply commute, so
+// the operand that needs its high half first simply goes to source 0; a complex product needs the high halves of
+// BOTH factors for its real part, so its second half is two plain FMAs.  tools/pk_scan.py --strict (run by
+// tests/test_host.py) fails the build of any kernel that contains the form and can share a SIMD.
 typedef float cplx __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return a + b; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return a - b; }
@@ -86,24 +95,43 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return a - b; }
 __device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) { return cplx{a.x + b.y, a.y - b.x}; }
 __device__ __forceinline__ cplx csub_mi(cplx a, cplx b) { return cplx{a.x - b.y, a.y + b.x}; }
 __device__ __forceinline__ cplx cmul(cplx a, cplx w) { return cplx{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-#else
-// a + (-i) b = (a.x + b.y, a.y - b.x)
+#elif defined(PPG_FE_R2_ARITH)
+// round 2's forms (source 1 swapped): the reproducer's arithmetic, with -DPPG_FE_R2
 __device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) {
     cplx r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// a - (-i) b = (a.x - b.y, a.y + b.x)
 __device__ __forceinline__ cplx csub_mi(cplx a, cplx b) {
     cplx r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// a w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x): (a.x, a.x) * w, then (a.y, a.y) * (-w.y, w.x) added
 __device__ __forceinline__ cplx cmul(cplx a, cplx w) {
     cplx t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+#else
+// a + (-i) b = (b.y + a.x, -b.x + a.y): b, swapped, is source 0
+__device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) {
+    cplx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+// a - (-i) b = (-b.y + a.x, b.x + a.y)
+__device__ __forceinline__ cplx csub_mi(cplx a, cplx b) {
+    cplx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+// a w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x): (a.x, a.x) * w packed (a is source 0), then -a.y w.y and a.y w.x on top
+__device__ __forceinline__ cplx cmul(cplx a, cplx w) {
+    cplx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r.x) : "v"(a.y), "v"(w.y), "v"(t.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "v"(a.y), "v"(w.x), "v"(t.y));
     return r;
 }
 #endif
