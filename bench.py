@@ -254,13 +254,24 @@ def run_c2(args, rank, world, local_rank, use_dist):
         start = time.perf_counter()
         for _ in range(args.steps):
             out = step(engine)
+        # this rank's own time to ITS synchronize (before the closing barrier): which rank bends a scaling curve
+        torch.cuda.synchronize()
+        own = time.perf_counter() - start
         barrier()
         elapsed = time.perf_counter() - start
         if use_dist:
             worst = torch.tensor([elapsed], device='cuda' if nccl else 'cpu', dtype=torch.float64)
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)
             elapsed = float(worst.item())
+            mine = torch.tensor([own], device='cuda' if nccl else 'cpu', dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank[:] = [float(t.item()) for t in every]
+        else:
+            per_rank[:] = [own]
         return elapsed, out
+
+    per_rank = []
 
     def prewarm(engine=model):
         """Disclosed, untimed: the same step for >= --prewarm-s seconds of wall time, so that the K timed
@@ -299,6 +310,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
     # through the five launches of a step; two event records per launch cost
     # ~1.5 us each on the stream, 1.5 % of the step if every launch is timed)
     elapsed, out = timed_block()
+    rank_ms = [1e3 * t / args.steps for t in per_rank]
     ffn_ms, ffn_samples = model.profile_read()['ffn']
     model.profile(False)
     # two more blocks of the same K steps: how much the figure moves from block to block
@@ -413,6 +425,8 @@ def run_c2(args, rank, world, local_rank, use_dist):
         'prewarm_s': prewarm_seconds,
         'prewarm_steps': prewarm_steps,
         'ms_per_step': ms_per_step,
+        # every rank's own time to finish its K steps (before the closing barrier), in rank order
+        'per_rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'all': rank_ms},
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,

@@ -590,5 +590,9 @@ struct Gemm32Args {
     char* out16;              // 16-bit [M][N] or null
     int M, N, K;              // N % 256 == 0, K % 128 == 0
     int act_fn;               // 0 none, 1 ReLU, 2 GELU
+    // rows past an item's valid frames come out as zeros (HF: hidden_states[~mask] = 0 behind the feature projection):
+    // item b owns rows b * rows_per_item .., valid frames in win[b].valid; null: every row is kept
+    const PpgWindow* win;
+    int rows_per_item;
 };
 

@@ -1926,6 +1926,7 @@ struct PpgW2v2Body {
     float eps = 1e-5f;
     float* pn_g = nullptr; float* pn_b = nullptr;
     char* proj_w = nullptr; float* proj_b = nullptr;
+    char* proj_img = nullptr;      // the feature projection as gemm32 fragment images (16-bit modes)
     char* pos_w = nullptr; float* pos_b = nullptr;
     float* en_g = nullptr; float* en_b = nullptr;
     struct Layer { char* wqkv; float* bqkv; char* wo; float* bo; float* g1; float* e1; char* w1; float* b1; char* w2; float* b2; float* g2; float* e2;
@@ -1987,6 +1988,19 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     if ((rc = upload_f32(E, w->proj_norm_weight, 512, 0, &m->pn_g))) return rc;
     if ((rc = upload_f32(E, w->proj_norm_bias, 512, 0, &m->pn_b))) return rc;
     if ((rc = paired(w->proj_weight, H, 512, &m->proj_w))) return rc;
+    // [N / 256][wave][K / 128][rb][8 K-steps] fragments: lane l = (row phi(l & 31) of the block, k 8 (l >> 5) .. + 7)
+    auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+    auto image = [&](const float* src, int N, int K, char** dst) {
+        const int chunks = K / 128, frags = (N / 256) * 4 * chunks * 16;
+        return upload_matrix(E, frags * 64, 8, frags * 64, 8,
+                             [&](int r, int j) {
+                                 const int f = r >> 6, ln = r & 63;
+                                 const int ks = f & 7, rb = (f >> 3) & 1, c = (f >> 4) % chunks, wv = ((f >> 4) / chunks) & 3, p = (f >> 4) / chunks / 4;
+                                 const int n = 256 * p + 64 * wv + 32 * rb + phi(ln & 31), k = 128 * c + 16 * ks + 8 * (ln >> 5) + j;
+                                 return src[(size_t)n * K + k];
+                             }, dst);
+    };
+    if (m->gemm32 && (rc = image(w->proj_weight, H, 512, &m->proj_img))) return rc;
     if ((rc = upload_f32(E, w->proj_bias, H, 0, &m->proj_b))) return rc;
     {   // W'[n][tap * gpt * KG + c] = w[n][c][tap] for c < 48 (n's own group), 0 for the pad channels; plain row order
         const int taps = m->taps, kk = m->gpt * E->KG;
@@ -2032,18 +2046,6 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
         if ((rc = upload_f32(E, lw.norm2_bias, H, 0, &d.e2))) return rc;
         d.wo_img = d.w1_img = d.w2_img = nullptr;
         if (m->gemm32) {
-            // [N / 256][wave][K / 128][rb][8 K-steps] fragments: lane l = (row phi(l & 31) of the block, k 8 (l >> 5) .. + 7)
-            auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
-            auto image = [&](const float* src, int N, int K, char** dst) {
-                const int chunks = K / 128, frags = (N / 256) * 4 * chunks * 16;
-                return upload_matrix(E, frags * 64, 8, frags * 64, 8,
-                                     [&](int r, int j) {
-                                         const int f = r >> 6, ln = r & 63;
-                                         const int ks = f & 7, rb = (f >> 3) & 1, c = (f >> 4) % chunks, wv = ((f >> 4) / chunks) & 3, p = (f >> 4) / chunks / 4;
-                                         const int n = 256 * p + 64 * wv + 32 * rb + phi(ln & 31), k = 128 * c + 16 * ks + 8 * (ln >> 5) + j;
-                                         return src[(size_t)n * K + k];
-                                     }, dst);
-            };
             if ((rc = image(lw.out_weight, H, H, &d.wo_img))) return rc;
             if ((rc = image(lw.ffn1_weight, F, H, &d.w1_img))) return rc;
             if ((rc = image(lw.ffn2_weight, H, F, &d.w2_img))) return rc;
@@ -2162,7 +2164,10 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         for (int k = 0; k < R / 16; ++k) hb[b * (R / 16) + k] = b;
         for (int q0 = 0; q0 < frames; q0 += 64) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, 0, 0};
     }
-    HIP_OK(hipMemsetAsync(base + L.ln, 0, L.hid - L.ln, s));    // padding rows, slack columns: finite (masked keys are still multiplied)
+    // padding rows, slack rows / columns of the OPERAND buffers: finite (masked keys are still multiplied).  The fp32
+    // residual buffers X and P (half of the bytes) are written in full by the projection / every GEMM epilogue.
+    HIP_OK(hipMemsetAsync(base + L.ln, 0, L.x - L.ln, s));
+    HIP_OK(hipMemsetAsync(base + L.xb, 0, L.hid - L.xb, s));
     HIP_OK(hipMemcpyAsync(base, slot.staging, table_bytes, hipMemcpyHostToDevice, s));
     HIP_OK(hipEventRecord(slot.uploaded, s));
     const PpgWindow* d_win = reinterpret_cast<const PpgWindow*>(base + L.win);
@@ -2203,7 +2208,13 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
     // feature projection: LayerNorm(512) -> Linear, rows past the valid frames zeroed (HF: hidden_states[~mask] = 0)
     LAUNCH_OK(ppg::launch_w2v2_layernorm(prec, 512, features, nullptr, m->pn_g, m->pn_b, (long)batch * frames, frames, R, m->eps,
                                          sz == 2 ? nullptr : reinterpret_cast<float*>(ln), sz == 2 ? ln : nullptr, s), "w2v2 projection LayerNorm");
-    {
+    if (m->gemm32) {
+        // (linear_kernel's 16-token waves re-read the 768 x 512 weights per 64 rows: 205 us for 6.4 GFLOP)
+        Gemm32Args g{};
+        g.x = ln; g.w_img = m->proj_img; g.bias = m->proj_b; g.out32 = X; g.out16 = Xb; g.M = M; g.N = H; g.K = 512;
+        g.win = d_win; g.rows_per_item = R;
+        LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 projection");
+    } else {
         LinearArgs a = general(ln, 512, m->proj_w, m->proj_b, H);
         a.zero_invalid = 1; a.out32 = X; a.out_rows = xb_out; a.out_ld = H;
         LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, a, H / 256, s), "w2v2 projection");

@@ -170,6 +170,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             if (!inside) continue;
+            if (a.win) {
+                const int item = m / a.rows_per_item;
+                if (m - item * a.rows_per_item >= a.win[item].valid) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) y[i] = 0.f;
+                }
+            }
             if (a.out32) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)

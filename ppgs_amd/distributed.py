@@ -40,54 +40,78 @@ def _cpulist(text):
     return cpus
 
 
-def bind_cpus(local_rank, local_world, device=None):
-    """Pin this rank's process (its launch thread, and the reader / writer threads it spawns later) to its
-    own slice of host cores: the cores of the NUMA node its GPU hangs off when sysfs tells, split among the
-    ranks that share the node -- otherwise an equal slice of the cores the process may use.  Eight ranks
-    each running a ~13-launch / 0.7 ms Python loop plus I/O threads on one box otherwise migrate over all
-    cores and across sockets.  Returns the sorted core list (empty: nothing was changed).
-    PPGS_AMD_BIND_CPUS=0 disables."""
-    if os.environ.get('PPGS_AMD_BIND_CPUS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
-        return []
-    allowed = sorted(os.sched_getaffinity(0))
+def cpu_slice(local_rank, local_world, allowed, gpu_nodes, node_cpus):
+    """The cores rank `local_rank` of `local_world` is pinned to (pure function; bind_cpus feeds it from sysfs).
+
+    allowed: cores the process may use; gpu_nodes[r]: NUMA node of rank r's GPU (-1 unknown); node_cpus[n]: cores of
+    node n.  A rank whose GPU's node is known gets an equal slice of that node's allowed cores, shared with the other
+    ranks whose GPUs hang off the same node; otherwise (unknown node, or a node with fewer than two cores per rank) an
+    equal slice of all allowed cores.  Empty list: leave the affinity alone."""
+    allowed = sorted(allowed)
     local_world = max(int(local_world), 1)
     if len(allowed) < 2 * local_world:
         return []
-    def node_of(index):
-        try:
-            props = torch.cuda.get_device_properties(index)
-            bdf = f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0'
-            with open(f'/sys/bus/pci/devices/{bdf}/numa_node') as handle:
-                return int(handle.read())
-        except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
-            return -1
-    cpus = None
-    if torch.cuda.is_available():
-        count = torch.cuda.device_count()
+    mine = gpu_nodes[local_rank] if local_rank < len(gpu_nodes) else -1
+    if mine >= 0 and mine in node_cpus:
+        ranks = [r for r in range(local_world) if r < len(gpu_nodes) and gpu_nodes[r] == mine]
+        cpus = sorted(set(node_cpus[mine]) & set(allowed))
+        if len(cpus) >= 2 * len(ranks):
+            per = len(cpus) // len(ranks)
+            slot = ranks.index(local_rank)
+            return cpus[slot * per:(slot + 1) * per]
+    per = len(allowed) // local_world
+    return allowed[local_rank * per:(local_rank + 1) * per]
 
-        def gpu_of(rank):
-            return (rank if device is None else device) % count
-        sharers = {}
-        for rank in range(local_world):
-            sharers.setdefault(node_of(gpu_of(rank)), []).append(rank)
-        mine = node_of(gpu_of(local_rank))
-        if mine >= 0:
-            try:
-                with open(f'/sys/devices/system/node/node{mine}/cpulist') as handle:
-                    node_cpus = sorted(_cpulist(handle.read()) & set(allowed))
-                ranks = sharers[mine]
-                if len(node_cpus) >= 2 * len(ranks):
-                    per = len(node_cpus) // len(ranks)
-                    slot = ranks.index(local_rank)
-                    cpus = node_cpus[slot * per:(slot + 1) * per]
-            except (OSError, KeyError, ValueError):
-                cpus = None
-    if not cpus:
-        per = len(allowed) // local_world
-        cpus = allowed[local_rank * per:(local_rank + 1) * per]
-    if not cpus:
+
+def gpu_numa_node(bdf, sysfs='/sys'):
+    """NUMA node of the PCI device `bdf` (dddd:bb:dd.f), -1 when sysfs does not tell."""
+    try:
+        with open(os.path.join(sysfs, 'bus', 'pci', 'devices', bdf, 'numa_node')) as handle:
+            return int(handle.read())
+    except (OSError, ValueError):
+        return -1
+
+
+def numa_cpus(node, sysfs='/sys'):
+    try:
+        with open(os.path.join(sysfs, 'devices', 'system', 'node', f'node{node}', 'cpulist')) as handle:
+            return _cpulist(handle.read())
+    except (OSError, ValueError):
+        return set()
+
+
+def bind_cpus(local_rank, local_world, device=None, sysfs=None, bdfs=None, apply=True):
+    """Pin this rank's process (its launch thread, and the reader / writer threads it spawns later) to its
+    own slice of host cores: the cores of the NUMA node its GPU hangs off when sysfs tells, split among the
+    ranks that share the node -- otherwise an equal slice of the cores the process may use.  Eight ranks
+    each running a ~25-launch / 0.7 ms Python loop plus I/O threads on one box otherwise migrate over all
+    cores and across sockets.  Returns the sorted core list (empty: nothing was changed).
+    PPGS_AMD_BIND_CPUS=0 disables.  `sysfs` (default /sys, or PPGS_AMD_SYSFS_ROOT), `bdfs` (the PCI addresses of
+    the ranks' GPUs, default from the HIP device properties) and `apply=False` exist for tests/test_host.py, which
+    runs the function against a faked 2-node x 4-GPU tree."""
+    if os.environ.get('PPGS_AMD_BIND_CPUS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
         return []
-    os.sched_setaffinity(0, cpus)
+    sysfs = sysfs or os.environ.get('PPGS_AMD_SYSFS_ROOT', '/sys')
+    allowed = sorted(os.sched_getaffinity(0))
+    local_world = max(int(local_world), 1)
+    if bdfs is None:
+        bdfs = []
+        if torch.cuda.is_available():
+            count = torch.cuda.device_count()
+            for rank in range(local_world):
+                try:
+                    props = torch.cuda.get_device_properties((rank if device is None else device) % count)
+                    bdfs.append(f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0')
+                except (AttributeError, RuntimeError, AssertionError):
+                    bdfs.append(None)
+    gpu_nodes = [gpu_numa_node(bdf, sysfs) if bdf else -1 for bdf in bdfs]
+    node_cpus = {node: numa_cpus(node, sysfs) for node in set(gpu_nodes) if node >= 0}
+    if sysfs != '/sys' and node_cpus:
+        # (a faked tree describes a machine that is not this one: its core numbers are the universe)
+        allowed = sorted(set().union(*node_cpus.values()))
+    cpus = cpu_slice(local_rank, local_world, allowed, gpu_nodes, node_cpus)
+    if cpus and apply:
+        os.sched_setaffinity(0, cpus)
     return cpus
 
 

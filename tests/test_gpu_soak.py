@@ -88,6 +88,35 @@ def test_soak_frontend_beside_sdpa():
     assert bad == 0, f'{bad} of {STEPS} frontend launches beside SDPA differ'
 
 
+def test_frontend_beside_a_matrix_core_aggressor_on_its_own_simds():
+    """The mechanism itself: a synthetic kernel that spins on v_mfma_f32_16x16x32_bf16 with 16 registers
+    and NO LDS fits beside the frontend's workgroups on their SIMDs even though those own the CU's LDS -- the
+    situation in which round 2's arithmetic (v_pk_*_f32 with op_sel on source 1) got 80 of 240 launches wrong."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'bin', 'libaggressors.so')
+    if not os.path.exists(path):
+        pytest.skip('tools/bin/libaggressors.so not built (tools/probes/build.sh; __graft_entry__.build() does it)')
+    lib = ctypes.CDLL(path)
+    lib.aggressor_launch.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+    gen = torch.Generator().manual_seed(1234)
+    audio = (0.1 * torch.randn(32, 1, 160000, generator=gen)).cuda()
+    reference = ppgs_amd.preprocess.mel.from_audios(audio).clone()
+    src, sink = torch.randn(1 << 20, device='cuda'), torch.zeros(256, device='cuda')
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device='cuda')
+    for rep in range(60):
+        with torch.cuda.stream(a):
+            for _ in range(2):      # mask 2 = v_mfma_f32_16x16x32_bf16 only; ~400 us per launch
+                assert lib.aggressor_launch(2, 512, 1500, 0, src.data_ptr(), sink.data_ptr(), a.cuda_stream) == 0
+        with torch.cuda.stream(b):
+            for _ in range(6):
+                bad += (ppgs_amd.preprocess.mel.from_audios(audio) != reference).any()
+        torch.cuda.synchronize()
+    assert int(bad) == 0, f'{int(bad)} of 360 frontend launches beside the MFMA aggressor differ'
+
+
 def test_soak_whole_steps_on_two_caller_streams_beside_sdpa():
     """The file pipeline's shape: whole steps (frontend + two-pipeline encode) alternating on two caller streams, so that
     one step's frontend runs beside the other's encoder, with the external aggressor on top."""

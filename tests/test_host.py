@@ -232,3 +232,35 @@ def test_no_kernel_is_exposed_to_the_packed_fp32_mfma_hazard():
     assert not pk_scan.vulnerable('v[0:1], v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]')
     assert not pk_scan.vulnerable('v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,0,1] op_sel_hi:[0,0,0]')
     assert not pk_scan.vulnerable('v[0:1], v[2:3], v[4:5]')
+
+
+def test_bind_cpus_against_a_faked_two_socket_eight_gpu_tree(tmp_path):
+    """The first real 8-GPU run must not be the first execution of the binding logic: a faked sysfs tree of the usual
+    MI355X box -- 2 NUMA nodes x 96 cores (+ SMT siblings 192..383), 4 GPUs per node -- gives every rank a disjoint
+    slice of its own GPU's node; a GPU without a numa_node file falls back to the equal split."""
+    sysfs = tmp_path / 'sys'
+    bdfs = []
+    for gpu in range(8):
+        bdf = f'0000:{0x05 + 0x10 * gpu:02x}:00.0'
+        bdfs.append(bdf)
+        device = sysfs / 'bus' / 'pci' / 'devices' / bdf
+        device.mkdir(parents=True)
+        (device / 'numa_node').write_text(f'{gpu // 4}\n')
+    for node in range(2):
+        directory = sysfs / 'devices' / 'system' / 'node' / f'node{node}'
+        directory.mkdir(parents=True)
+        (directory / 'cpulist').write_text(f'{96 * node}-{96 * node + 95},{192 + 96 * node}-{192 + 96 * node + 95}\n')
+    slices = [distributed.bind_cpus(rank, 8, sysfs=str(sysfs), bdfs=bdfs, apply=False) for rank in range(8)]
+    assert all(len(cpus) == 48 for cpus in slices)
+    for rank, cpus in enumerate(slices):
+        node = rank // 4
+        assert all((96 * node <= c < 96 * node + 96) or (192 + 96 * node <= c < 192 + 96 * node + 96) for c in cpus), rank
+    flat = [c for cpus in slices for c in cpus]
+    assert len(flat) == len(set(flat)) == 384
+    # 4 ranks on a 8-GPU node: the ranks still follow THEIR GPUs' nodes
+    slices = [distributed.bind_cpus(rank, 4, sysfs=str(sysfs), bdfs=bdfs[2:6], apply=False) for rank in range(4)]
+    assert [min(c) // 96 % 2 for c in slices] == [0, 0, 1, 1] and all(len(c) == 96 for c in slices)
+    # the pure rule: unknown node -> equal split of what is allowed; too few cores -> hands off
+    assert distributed.cpu_slice(1, 2, range(16), [-1, -1], {}) == list(range(8, 16))
+    assert distributed.cpu_slice(0, 8, range(8), [0] * 8, {0: set(range(8))}) == []
+    assert distributed.cpu_slice(3, 4, range(64), [0, 0, 1, 1], {0: set(range(32)), 1: set(range(32, 64))}) == list(range(48, 64))

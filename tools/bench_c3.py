@@ -74,12 +74,17 @@ def main():
             conv_flops += 2 * t * 512 * k * (1 if layer == 0 else 512)
         conv_flops *= 16
         hip_ms = timed(lambda: encoder(audio))
+        # PPGS_BENCH_C3_NATIVE_ONLY=1 (tests/prof_configs.sh): no PyTorch-ROCm comparison legs, so that a rocprofv3 trace
+        # of this command holds this package's kernels only
+        native_only = bool(os.environ.get('PPGS_BENCH_C3_NATIVE_ONLY'))
         with torch.no_grad():
-            torch_ms = timed(lambda: hf.feature_extractor(audio), steps=5, warmup=2)
-            extract = hf.feature_extractor(audio).transpose(1, 2)
-            body_ms = timed(lambda: hf.encoder(hf.feature_projection(extract)[0]), steps=5, warmup=2)
-            with torch.autocast('cuda', dtype=torch.float16):
-                body16_ms = timed(lambda: hf.encoder(hf.feature_projection(extract)[0]), steps=5, warmup=2)
+            extract = encoder(audio) if native_only else hf.feature_extractor(audio).transpose(1, 2)
+            torch_ms = body_ms = body16_ms = float('nan')
+            if not native_only:
+                torch_ms = timed(lambda: hf.feature_extractor(audio), steps=5, warmup=2)
+                body_ms = timed(lambda: hf.encoder(hf.feature_projection(extract)[0]), steps=5, warmup=2)
+                with torch.autocast('cuda', dtype=torch.float16):
+                    body16_ms = timed(lambda: hf.encoder(hf.feature_projection(extract)[0]), steps=5, warmup=2)
         body = E.W2v2Body(hf, 0, precision)
         frames = extract.shape[1]
         body_flops = 16 * frames * (2 * 512 * 768 + 2 * 48 * 128 * 768 + 12 * (8 * 768 * 768 + 4 * 768 * 3072 + 4 * frames * 768))
