@@ -649,17 +649,24 @@ def rank_main(args):
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        if alias:
+        if alias or os.environ.get('PPGS_BENCH_BACKEND') == 'gloo':
             dist.init_process_group('gloo', rank=rank, world_size=world)
+        elif os.environ.get('PPGS_BENCH_BACKEND') == 'nccl-eager':
+            # (experiment only.  With device_id= PyTorch builds the communicator at init and binds the group to the
+            # device; a process in that state ran the allocation-heavy C4 pass -- 496 batch shapes, new tensors per
+            # batch -- 60 % slower on the HOST side: 624 ms against 387 ms for the same kernels, one rank,
+            # profiles/r4_c4_process_group.txt.  The lazy group below, whose communicator appears with the first
+            # barrier, costs nothing.)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', rank=rank, world_size=world)
     line = None
     try:
         line = (run_c2 if args.workload == 'c2' else run_c4)(args, rank, world, local_rank, use_dist)
         if rank == 0 and use_dist:
-            line['backend'] = 'gloo: PPGS_BENCH_ALIAS_GPUS dry run, ranks share GPUs -- NOT a multi-GPU measurement' if alias else 'nccl (RCCL)'
-            line['rccl_world_size' if not alias else 'gloo_world_size'] = dist.get_world_size()
+            line['backend'] = ('gloo: PPGS_BENCH_ALIAS_GPUS dry run, ranks share GPUs -- NOT a multi-GPU measurement' if alias
+                               else ('nccl (RCCL)' if dist.get_backend() == 'nccl' else dist.get_backend()))
+            line['rccl_world_size' if dist.get_backend() == 'nccl' else 'gloo_world_size'] = dist.get_world_size()
             line['rank0_cpus'] = len(cpus)
     finally:
         if use_dist:

@@ -1,12 +1,30 @@
+# One gpurun call that produces every record of a round under gpurun_out/final_<tag>/ (copy what is to be judged
+# into profiles/):   bash tools/final_records.sh r4
 set -x
+tag=${1:-r4}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-timeout 400 python bench.py > gpurun_out/final/bench.log 2>&1; grep "^{" gpurun_out/final/bench.log | tail -1 > gpurun_out/final/r2_bench.json
-timeout 300 python bench.py --precision fp32 --no-alt > gpurun_out/final/bench_fp32.log 2>&1; grep "^{" gpurun_out/final/bench_fp32.log | tail -1 > gpurun_out/final/r2_bench_fp32.json
-PPGS_AMD_STREAMS=2 timeout 300 python bench.py --no-cpu --no-alt > gpurun_out/final/bench_s2.log 2>&1; grep "^{" gpurun_out/final/bench_s2.log | tail -1 > gpurun_out/final/r2_bench_streams2.json
-timeout 600 bash tests/prof.sh r2c > gpurun_out/final/prof.log 2>&1
-timeout 120 python tools/time_frontend.py > gpurun_out/final/time_frontend.txt 2>&1
-ls -la gpurun_out/final
-timeout 600 python tools/bench_c3.py > gpurun_out/final/c3.log 2>&1
-PPGS_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload c4 > gpurun_out/final/c4.log 2>&1
-timeout 300 python tools/bench_streaming.py > gpurun_out/final/c5.log 2>&1
+out=gpurun_out/final_$tag
+mkdir -p $out
+timeout 1800 python -m pytest tests -m gpu -q > $out/gputests.log 2>&1; tail -n 3 $out/gputests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -n 5 $out/smoke.log
+# the driver's command first (a fresh process, 20 steps), then the default line
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.log 2>&1; grep "^{" $out/bench_driver.log | tail -1 > $out/${tag}_bench.json
+timeout 400 python bench.py > $out/bench_default.log 2>&1; grep "^{" $out/bench_default.log | tail -1 > $out/${tag}_bench_1000steps.json
+PPGS_AMD_STREAMS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-alt > $out/bench_one.log 2>&1; grep "^{" $out/bench_one.log | tail -1 > $out/${tag}_one_pipeline_bench.json
+timeout 300 python bench.py --precision fp32 --no-alt --no-cpu --steps 20 --warmup 5 > $out/bench_fp32.log 2>&1; grep "^{" $out/bench_fp32.log | tail -1 > $out/${tag}_bench_fp32.json
+timeout 900 bash tests/prof.sh $tag > $out/prof.log 2>&1
+python tests/pmc_summary.py gpurun_out/prof_$tag/pmc*/bench_counter_collection.csv > $out/${tag}_pmc_summary.txt 2>$out/pmc_summary.err
+find gpurun_out/prof_$tag/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats.csv
+# one pipeline under the profiler: the per-kernel whole-chip figures
+( cd /tmp && export TMPDIR=/tmp && PPGS_AMD_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_one/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-alt --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/prof_one.log 2>&1 )
+find gpurun_out/prof_${tag}_one/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_one_pipeline_kernel_stats.csv
+timeout 900 bash tests/prof_configs.sh $tag > $out/prof_configs.log 2>&1
+for c in c3 c5 c5stream; do cp gpurun_out/prof_${tag}_$c/kernel_stats.csv $out/${tag}_kernel_stats_$c.csv; done
+timeout 600 python tools/bench_c3.py > $out/c3.log 2>&1; grep "^{" $out/c3.log | tail -1 > $out/${tag}_bench_c3.json
+PPGS_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload c4 > $out/c4.log 2>&1; grep "^{" $out/c4.log | tail -1 > $out/${tag}_bench_c4.json
+timeout 300 python tools/bench_streaming.py > $out/c5.log 2>&1; grep "^{" $out/c5.log | tail -1 > $out/${tag}_bench_c5.json
+# the N-rank host path on the one GPU present (gloo; NOT a multi-GPU measurement): 8 launch loops through one GPU's queues
+PPGS_BENCH_ALIAS_GPUS=1 timeout 600 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu --no-alt > $out/alias8.log 2>&1; grep "^{" $out/alias8.log | tail -1 > $out/${tag}_bench_alias8_dry_run.json
+timeout 120 python tools/time_frontend.py > $out/time_frontend.txt 2>&1
+timeout 200 python tools/two_stream_steps.py --streams 1 2 --steps 400 > $out/two_stream_steps.txt 2>&1
+ls -la $out
