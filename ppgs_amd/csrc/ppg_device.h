@@ -596,3 +596,17 @@ struct Gemm32Args {
     int rows_per_item;
 };
 
+// ppg_ffn32x2.hip: the FFN block in the fp16x2 mode on the feature-split machinery (96-token workgroups)
+struct Ffn32X2Args {
+    const char* xb;           // [M][H] as [32 hi | 32 lo] fp16 blocks (PrecX2 rows, 4 bytes per element): the operand copy of X
+    float* X;                 // fp32 [M][H]: residual in, LayerNorm-2 output out
+    char* xb_out;             // the operand copy of the result (may be xb)
+    const char* w1_img;       // [F/128 chunks][4 waves][W1 hi: 16 K-steps | W1 lo: 16 K-steps] fragments of 1 KiB
+    const char* w2_img;       // [F/128 chunks][4 waves][W2 hi: (2 row blocks, 8 K-steps) | W2 lo] fragments
+    const float* b1; const float* b2; const float* g2; const float* e2;
+    int M, F, H;
+    // the attention block's tail in front (wo_img != null): x1 = LayerNorm1(X + bo + Wo ao), ao in the rows' format
+    const char* ao;
+    const char* wo_img;       // [4 waves][K half][Wo hi: (2 row blocks, 8 K-steps) | Wo lo] fragments
+    const float* bo; const float* g1; const float* e1;
+};

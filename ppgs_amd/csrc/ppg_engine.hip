@@ -222,6 +222,8 @@ struct DevLayer {
     float *g1, *e1, *g2, *e2;
     // fragment images of the feature-split layer kernel (ppg_layer32.hip), 16-bit modes with hidden 256
     char* wo_img = nullptr; char* w1_img = nullptr; char* w2_img = nullptr; char* wq_img = nullptr;
+    // hi + lo fragment images of the fp16x2 mode's feature-split FFN kernel (ppg_ffn32x2.hip), hidden 256
+    char* w1x_img = nullptr; char* w2x_img = nullptr; char* wox_img = nullptr;
 };
 
 struct DevPlan {
@@ -275,6 +277,7 @@ struct PpgEngine {
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
     unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
+    int ffn32x2 = 2;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 2 = out-proj + LN1 + FFN + LN2 of a layer in ONE feature-split launch (ppg_ffn32x2.hip), 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
     bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
     bool subtile = true;     // layer32 path, hidden 256: workgroups of two token blocks (three per 160-token tile) when whole tiles would leave two thirds of the CUs idle (PPGS_AMD_SUBTILE=0: whole tiles always)
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
@@ -925,6 +928,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
     if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
     if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
+    if (const char* s = getenv("PPGS_AMD_FFN32X2")) e->ffn32x2 = atoi(s);
     if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
     if (const char* s = getenv("PPGS_AMD_STREAM_ONE_PASS")) e->stream_one_pass = atoi(s) != 0;
     if (const char* s = getenv("PPGS_AMD_STREAMS_MIN_ROWS")) e->stream_min_rows = std::max(1, atoi(s));
@@ -1115,6 +1119,45 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
                                          : 2 * H + pair_row(32 * RB * w + 32 * rb + (ln & 31));
                 return wq[(size_t)row * H + panel_k(ks, ln, j)];
             }, &d.wq_img);
+            if (rc) return rc;
+        }
+        if (e->split && e->ffn32x2 && H == 256 && F % 128 == 0) {
+            // ppg_ffn32x2.hip: every A fragment twice, as the fp16 hi plane and the fp16 lo plane of the fp32 weight.
+            // W1: [chunk][wave][plane][ks], rows natural, K natural (the panel is loaded in natural order);
+            // W2: [chunk][wave][plane][rb][ks8], rows in the order phi, K = the chunk's h in accumulator order
+            auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+            auto image2 = [&](int groups, auto get, char** dst) {      // get(group, fragment 0..15, lane, j) -> fp32 weight
+                std::vector<uint16_t> tmp((size_t)groups * 32 * 512);
+                for (int g = 0; g < groups; ++g)
+                    for (int f = 0; f < 16; ++f)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = get(g, f, ln, j);
+                                const uint16_t hi = host_f16(v);
+                                tmp[((size_t)g * 32 + f) * 512 + ln * 8 + j] = hi;
+                                tmp[((size_t)g * 32 + 16 + f) * 512 + ln * 8 + j] = host_f16(v - host_f16_to_f32(hi));
+                            }
+                return upload(E, tmp.data(), tmp.size() * 2, reinterpret_cast<void**>(dst));
+            };
+            const float* w1 = wts->linear1_weight[l];
+            rc = image2(F / 128 * 4, [&](int g, int ks, int ln, int j) {
+                const int w = g & 3, ch = g >> 2;
+                return w1[(size_t)(ch * 128 + 32 * w + (ln & 31)) * H + 16 * ks + 8 * (ln >> 5) + j];
+            }, &d.w1x_img);
+            if (rc) return rc;
+            const float* w2 = wts->linear2_weight[l];
+            rc = image2(F / 128 * 4, [&](int g, int f, int ln, int j) {
+                const int w = g & 3, ch = g >> 2, rb = f >> 3, ks = f & 7;
+                return w2[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * F + ch * 128 + 32 * (ks >> 1) + 16 * (ks & 1) +
+                          8 * (j >> 2) + 4 * (ln >> 5) + (j & 3)];
+            }, &d.w2x_img);
+            if (rc) return rc;
+            // Wo: [wave][K half][plane][rb][ks8], K natural (the attention output's)
+            const float* wo = wts->out_proj_weight[l];
+            rc = image2(4 * 2, [&](int g, int f, int ln, int j) {
+                const int kh = g & 1, w = g >> 1, rb = f >> 3, ks = f & 7;
+                return wo[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * H + 16 * (8 * kh + ks) + 8 * (ln >> 5) + j];
+            }, &d.wox_img);
             if (rc) return rc;
         }
         if ((rc = upload_f32(E, in_b.data(), 3 * H, 0, &d.bqkv))) return rc;
@@ -1336,7 +1379,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             continue;
         }
         const bool fuse_op = e->ffn_fused && e->op_fused && ws.ffn_splits == 1;
-        if (!fuse_op) {
+        const bool x2_layer = e->split && e->ffn32x2 > 0 && d.w1x_img && 2 * ((M + ppg::ffn32x2_tokens() - 1) / ppg::ffn32x2_tokens()) >= e->num_cus;
+        if (!fuse_op && !(x2_layer && e->ffn32x2 >= 2)) {
             Timed t(e, PPG_K_OUTPROJ_LN, s);
             LinearArgs a = base_args();
             a.act = ao; a.lda_bytes = H * e->sz;
@@ -1347,7 +1391,14 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         }
         {
             Timed t(e, PPG_K_FFN, s);
-            if (e->ffn_fused) {
+            if (x2_layer) {
+                Ffn32X2Args a{};
+                a.xb = Xb; a.X = X; a.xb_out = Xb; a.w1_img = d.w1x_img; a.w2_img = d.w2x_img;
+                a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2; a.M = M; a.F = F; a.H = H;
+                if (e->ffn32x2 >= 2) { a.ao = ao; a.wo_img = d.wox_img; a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; }
+                qkv_done = false;
+                LAUNCH_OK(ppg::launch_ffn32x2(a, s), "ffn32x2");
+            } else if (e->ffn_fused) {
                 FfnArgs a{};
                 a.X = X; a.Xb = Xb; a.W1 = d.w1; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
                 a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = M; a.dbg = l == 0 ? e->ffn_dbg : nullptr;

@@ -1470,3 +1470,33 @@ def test_fp16x2_mode_meets_the_fp32_bar(golden):
     assert np.abs(ppg.mean(-1).numpy() - g6['ppg_mean']).max() < FP32_TOL
     with pytest.raises((ValueError, E.PpgError)):
         E.Engine(W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512), 0, 'fp16x2')
+
+
+def test_fp16x2_feature_split_ffn_vs_token_split_and_oracle(monkeypatch):
+    """fp16x2, batches that fill the chip: the FFN block runs on ppg_ffn32x2.hip (96-token workgroups of the
+    feature-split machinery, hi + lo fragment images, three MFMAs per product) instead of the token-split
+    ffn_kernel<PrecX2> + reduce pass (PPGS_AMD_FFN32X2=0).  Both forms against each other on a uniform and on a
+    ragged batch (tile tails, windows of every length), seeded and sharpened checkpoints, and against the fp32
+    oracle on spot utterances: the fp32 bar, 1e-4."""
+    gen = torch.Generator().manual_seed(321)
+    feats = torch.randn(32, 80, 1000, generator=gen).half()
+    cases = [[1000] * 32, [1000, 997, 730, 501, 500, 499, 129, 33] * 4]
+    for seed, sharpen in ((1234, 1.0), (4321, 2.0)):
+        state = W.seeded_state_dict(seed=seed, sharpen=sharpen)
+        fused = E.Engine(state, 0, 'fp16x2')            # out-proj + LN1 + FFN + LN2 in one launch per layer
+        monkeypatch.setenv('PPGS_AMD_FFN32X2', '1')
+        ffn_only = E.Engine(state, 0, 'fp16x2')         # the FFN block only
+        monkeypatch.setenv('PPGS_AMD_FFN32X2', '0')
+        split = E.Engine(state, 0, 'fp16x2')
+        monkeypatch.delenv('PPGS_AMD_FFN32X2')
+        for lengths in cases:
+            a = fused.encode(feats.cuda(), lengths)
+            b = split.encode(feats.cuda(), lengths)
+            c = ffn_only.encode(feats.cuda(), lengths)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(a).all())
+            assert float((a - b).abs().max()) < 2e-5, (seed, lengths[:3])
+            assert float((c - b).abs().max()) < 2e-5, (seed, lengths[:3])
+            picks = [1, 30]
+            ref = O.from_features(state, feats[picks].float(), torch.tensor([lengths[i] for i in picks])).numpy()
+            assert np.abs(a[picks].cpu().numpy() - ref).max() < FP32_TOL, (seed, lengths[:3])
