@@ -609,4 +609,12 @@ struct Ffn32X2Args {
     const char* ao;
     const char* wo_img;       // [4 waves][K half][Wo hi: (2 row blocks, 8 K-steps) | Wo lo] fragments
     const float* bo; const float* g1; const float* e1;
+    // the NEXT layer's Q / K / V projection behind LayerNorm-2 (wq_img != null; with wo_img only)
+    const char* wq_img;       // [4 waves][kind q, k, v][K half][hi: (2 row blocks, 8 K-steps) | lo] fragments
+    const float* bq;
+    char* qk_out;             // [M][2H] (q | k) as [32 hi | 32 lo] rows
+    char* vt_out;             // transposed V [H][vt_ld], columns as [32 hi | 32 lo] blocks
+    int vt_ld;
+    const int* blk_win;
+    const PpgWindow* win;
 };

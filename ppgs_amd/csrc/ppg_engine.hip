@@ -223,7 +223,7 @@ struct DevLayer {
     // fragment images of the feature-split layer kernel (ppg_layer32.hip), 16-bit modes with hidden 256
     char* wo_img = nullptr; char* w1_img = nullptr; char* w2_img = nullptr; char* wq_img = nullptr;
     // hi + lo fragment images of the fp16x2 mode's feature-split FFN kernel (ppg_ffn32x2.hip), hidden 256
-    char* w1x_img = nullptr; char* w2x_img = nullptr; char* wox_img = nullptr;
+    char* w1x_img = nullptr; char* w2x_img = nullptr; char* wox_img = nullptr; char* wqx_img = nullptr;
 };
 
 struct DevPlan {
@@ -277,7 +277,7 @@ struct PpgEngine {
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
     unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
-    int ffn32x2 = 2;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 2 = out-proj + LN1 + FFN + LN2 of a layer in ONE feature-split launch (ppg_ffn32x2.hip), 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
+    int ffn32x2 = 3;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 3 = out-proj + LN1 + FFN + LN2 + the next layer's Q/K/V in ONE feature-split launch per layer (ppg_ffn32x2.hip), 2 = without the Q/K/V tail, 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
     bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
     bool subtile = true;     // layer32 path, hidden 256: workgroups of two token blocks (three per 160-token tile) when whole tiles would leave two thirds of the CUs idle (PPGS_AMD_SUBTILE=0: whole tiles always)
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
@@ -1159,6 +1159,15 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
                 return wo[(size_t)(64 * w + 32 * rb + phi(ln & 31)) * H + 16 * (8 * kh + ks) + 8 * (ln >> 5) + j];
             }, &d.wox_img);
             if (rc) return rc;
+            // W_qkv of THIS layer (the previous layer's launch runs it as its tail): [wave][kind][K half][plane][rb][ks8];
+            // Q and K rows in the order phi, V rows in attn_kernel's tile order (V^T row r = natural feature pair_row(r))
+            const float* wq = in_w.data();
+            rc = image2(4 * 3 * 2, [&](int g, int f, int ln, int j) {
+                const int kh = g & 1, kind = (g >> 1) % 3, w = g / 6, rb = f >> 3, ks = f & 7;
+                const int row = kind < 2 ? kind * H + 64 * w + 32 * rb + phi(ln & 31) : 2 * H + pair_row(64 * w + 32 * rb + (ln & 31));
+                return wq[(size_t)row * H + 16 * (8 * kh + ks) + 8 * (ln >> 5) + j];
+            }, &d.wqx_img);
+            if (rc) return rc;
         }
         if ((rc = upload_f32(E, in_b.data(), 3 * H, 0, &d.bqkv))) return rc;
         if ((rc = upload_f32(E, wts->out_proj_bias[l], H, 0, &d.bo))) return rc;
@@ -1396,7 +1405,12 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 a.xb = Xb; a.X = X; a.xb_out = Xb; a.w1_img = d.w1x_img; a.w2_img = d.w2x_img;
                 a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2; a.M = M; a.F = F; a.H = H;
                 if (e->ffn32x2 >= 2) { a.ao = ao; a.wo_img = d.wox_img; a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; }
-                qkv_done = false;
+                qkv_done = e->ffn32x2 >= 3 && l + 1 < c.num_layers;
+                if (qkv_done) {
+                    const DevLayer& nx = e->layers[l + 1];
+                    a.wq_img = nx.wqx_img; a.bq = nx.bqkv; a.qk_out = qk; a.vt_out = vt; a.vt_ld = ws.vt_ld;
+                    a.blk_win = grp.d_blk; a.win = grp.d_win;
+                }
                 LAUNCH_OK(ppg::launch_ffn32x2(a, s), "ffn32x2");
             } else if (e->ffn_fused) {
                 FfnArgs a{};

@@ -48,7 +48,7 @@ struct OffB2 { static constexpr int at(int i) { return (((i % 3) * 8 + i / 3) * 
 template <int KHALF> struct OffO1 { static constexpr int at(int i) { return (((i % 3) * XKS + 8 * KHALF + i / 6) * 2 + (i % 6) / 3) * 1024; } };
 template <int KHALF> struct OffO2 { static constexpr int at(int i) { return (((i % 3) * XKS + 8 * KHALF + i / 3) * 2) * 1024; } };
 
-template <bool OP>
+template <bool OP, bool QKV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn32x2_kernel(Ffn32X2Args a) {
     using P = PrecF16;                  // the planes are fp16: v_mfma_f32_32x32x16_f16
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,6 +160,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
+    // the 16 results of block (t, rb), split into hi + lo, into the panel: a lane's 16 values are K-step 4 wave + 2 rb + hh
+    // of its token -- both halves of that fragment's lane pair (tok, tok + 32)
+    auto panel_write = [&](int t, int rb, const f32x16& y) {
+        const uint32_t frag = lds0 + X_PANEL + (uint32_t)(((t * XKS + 4 * wave + 2 * rb + hh) * 2) * 1024 + tok * 16);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 fh, fl;
+            uint32_t* ph = reinterpret_cast<uint32_t*>(&fh);
+            uint32_t* pl = reinterpret_cast<uint32_t*>(&fl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) PrecX2::split2(y[8 * half + 2 * j], y[8 * half + 2 * j + 1], ph[j], pl[j]);
+            const uint32_t addr = frag + half * 512;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(fh) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(addr), "v"(fl) : "memory");
+        }
+    };
     if constexpr (OP) {
         // ---- out-projection: image order [wave][K half][Wo hi (rb, ks8) | Wo lo (rb, ks8)]; x1 = LN1(X + bo + Wo ao)
         const char* wo = a.wo_img + ((size_t)wave * 64) * 1024;
@@ -197,22 +213,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }(), ...);
         }(std::integer_sequence<int, 0, 1>{});
-        // x1: stays in the accumulators (the FFN sums on top of its own residual) and goes into the panel: a lane's 16
-        // values are K-step 4 wave + 2 rb + hh of its token -- both halves of that fragment's lane pair (tok, tok + 32)
-        layer_norm(std::true_type{}, lnp1, [&](int t, int rb, int, const f32x16& y) {
-            const uint32_t frag = lds0 + X_PANEL + (uint32_t)(((t * XKS + 4 * wave + 2 * rb + hh) * 2) * 1024 + tok * 16);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                u32x4 fh, fl;
-                uint32_t* ph = reinterpret_cast<uint32_t*>(&fh);
-                uint32_t* pl = reinterpret_cast<uint32_t*>(&fl);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) PrecX2::split2(y[8 * half + 2 * j], y[8 * half + 2 * j + 1], ph[j], pl[j]);
-                const uint32_t addr = frag + half * 512;
-                asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(fh) : "memory");
-                asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(addr), "v"(fl) : "memory");
-            }
-        });
+        // x1: stays in the accumulators (the FFN sums on top of its own residual) and goes into the panel
+        layer_norm(std::true_type{}, lnp1, [&](int t, int rb, int, const f32x16& y) { panel_write(t, rb, y); });
         load16(s1, w1_of(0));
         vm_wait_all(s1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,11 +307,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     vm_wait_all(s1);
 
     // ---- + b2 (+ the residual row, unless the accumulators started from it), LayerNorm-2, fp32 rows and the operand copy out
-    auto store = [&](int, int rb, int m, const f32x16& y) {
+    auto store = [&](int t, int rb, int m, const f32x16& y) {
+        if constexpr (QKV) panel_write(t, rb, y);            // x2: the B operand of the next layer's Q/K/V below
         if (m >= a.M) return;
         float* xrow = a.X + (size_t)m * XH + fbase + 32 * rb + 16 * hh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(xrow + 4 * q) = make_float4(y[4 * q + 0], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        if (QKV) return;                                     // (nobody reads the operand copy: x2 goes straight into the tail)
         // the 16 features 64 w + 32 rb + 16 hh .. of the [32 hi | 32 lo] copy: 32 bytes of the hi plane, lo 64 on
         char* brow = a.xb_out + (size_t)m * (XH * 4) + (2 * wave + rb) * 128 + hh * 32;
 #pragma unroll
@@ -325,6 +329,144 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     if constexpr (OP) layer_norm(std::false_type{}, lnp, store);
     else layer_norm(std::true_type{}, lnp, store);
+
+    if constexpr (QKV) {
+        // ---- the next layer's Q / K / V from the x2 panel: three projections of 288 MFMAs per wave, image order
+        // [wave][kind][K half][hi (rb, ks8) | lo (rb, ks8)].  Q and K leave as [32 hi | 32 lo] rows (a lane owns 16
+        // consecutive features of its token), V with the MFMA operands swapped, so that the accumulator comes out
+        // transposed: a lane owns one V^T row (tile order: natural feature pair_row(row)) and 16 tokens, whose columns
+        // inside a window's 32-token group sit at position 8 g + 4 e + r for token 16 e + 4 g + r (attn_kernel's PV
+        // fragment order), both planes.
+        const char* wq = a.wq_img + ((size_t)wave * 3 * 64) * 1024;
+        load16(s1, wq);
+        // transposed-V columns of the 16-token halves of every token block (as ppg_layer32.h qkv_tail)
+        int vcol[XTB][2];
+        bool valigned[XTB];
+        bool regular = m0 + XTOK <= a.M;      // every row exists, every block is one 32-token group: the store counts below are exact
+#pragma unroll
+        for (int t = 0; t < XTB; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mb = m0 + 32 * t + 16 * h;
+                vcol[t][h] = -1;
+                if (mb < a.M) {
+                    const int w = a.blk_win[mb >> 4];
+                    if (w >= 0) {
+                        const int ttb = mb - a.win[w].tok_off;
+                        vcol[t][h] = a.win[w].vt_off + (ttb >> 5) * 32 + 4 * ((ttb >> 4) & 1);
+                    }
+                }
+            }
+            valigned[t] = vcol[t][0] >= 0 && vcol[t][1] == vcol[t][0] + 4 && (vcol[t][0] & 31) == 0;
+            regular = regular && valigned[t];
+        }
+        vm_wait_all(s1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                     // the panel holds x2
+        // Stage = (projection, K half).  Its hi fragments are in set 1; the lo fragments travel into set 2 under the
+        // stage's first stream, the NEXT stage's hi fragments into set 1 under its second.  A projection's epilogue --
+        // bias, split, stores -- is issued behind those requests; vmcnt counts in order, so the wait for the fragments
+        // is vmcnt(stores of the epilogue) in a regular tile, not a wait for the stores' acknowledgement.
+        [&]<int... STAGE>(std::integer_sequence<int, STAGE...>) {
+            ([&] {
+                constexpr int KIND = STAGE / 2, KHALF = STAGE % 2;
+                constexpr bool SWAP = KIND == 2;
+                constexpr bool LAST = STAGE == 5;
+                const char* lo = wq + (size_t)(STAGE * 32 + 16) * 1024;
+                const char* nxt = wq + (size_t)((LAST ? STAGE : STAGE + 1) * 32) * 1024;
+                stream<OffO1<KHALF>, 8 * 6, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / 6, tb = i % 3;
+                    if constexpr (KHALF == 0 && i < 3) {
+                        yacc[0][tb] = SWAP ? P::mma32(bf, s1[0], zero) : P::mma32(s1[0], bf, zero);
+                        yacc[1][tb] = SWAP ? P::mma32(bf, s1[8], zero) : P::mma32(s1[8], bf, zero);
+                    } else {
+                        yacc[0][tb] = SWAP ? P::mma32(bf, s1[ks], yacc[0][tb]) : P::mma32(s1[ks], bf, yacc[0][tb]);
+                        yacc[1][tb] = SWAP ? P::mma32(bf, s1[8 + ks], yacc[1][tb]) : P::mma32(s1[8 + ks], bf, yacc[1][tb]);
+                    }
+                    if constexpr (i < 16) gload_frag<i>(s2[i], voff, lo);
+                });
+                vm_wait_all(s2);
+                stream<OffO2<KHALF>, 8 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / 3, tb = i % 3;
+                    yacc[0][tb] = SWAP ? P::mma32(bf, s2[ks], yacc[0][tb]) : P::mma32(s2[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = SWAP ? P::mma32(bf, s2[8 + ks], yacc[1][tb]) : P::mma32(s2[8 + ks], bf, yacc[1][tb]);
+                    if constexpr (!LAST && i < 16) gload_frag<i>(s1[i], voff, nxt);
+                });
+                if constexpr (KHALF == 1) {
+                    // epilogue of projection KIND (its stores queue behind the next stage's fragment requests)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        if constexpr (KIND < 2) {
+                            float4 b4[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(a.bq + XH * KIND + fbase + 32 * rb + 16 * hh + 4 * q);
+#pragma unroll
+                            for (int t = 0; t < XTB; ++t) {
+                                const int m = m0 + 32 * t + tok;
+                                if (m >= a.M) continue;
+                                const f32x16& c = yacc[rb][t];
+                                const float y[16] = {c[0] + b4[0].x, c[1] + b4[0].y, c[2] + b4[0].z, c[3] + b4[0].w, c[4] + b4[1].x, c[5] + b4[1].y, c[6] + b4[1].z, c[7] + b4[1].w,
+                                                     c[8] + b4[2].x, c[9] + b4[2].y, c[10] + b4[2].z, c[11] + b4[2].w, c[12] + b4[3].x, c[13] + b4[3].y, c[14] + b4[3].z, c[15] + b4[3].w};
+                                char* dst = a.qk_out + (size_t)m * (2 * XH * 4) + KIND * (XH * 4) + (2 * wave + rb) * 128 + hh * 32;
+#pragma unroll
+                                for (int s = 0; s < 2; ++s) {
+                                    u32x4 fh, fl;
+                                    uint32_t* ph = reinterpret_cast<uint32_t*>(&fh);
+                                    uint32_t* pl = reinterpret_cast<uint32_t*>(&fl);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) PrecX2::split2(y[8 * s + 2 * j], y[8 * s + 2 * j + 1], ph[j], pl[j]);
+                                    *reinterpret_cast<u32x4*>(dst + 16 * s) = fh;
+                                    *reinterpret_cast<u32x4*>(dst + 64 + 16 * s) = fl;
+                                }
+                            }
+                        } else {
+                            // lane = V^T row fbase + 32 rb + tok, registers 4 q + r = token 8 q + 4 hh + r of the block
+                            const float bv = a.bq[2 * XH + pair_row(fbase + 32 * rb + tok)];
+                            char* rowp = a.vt_out + (size_t)(fbase + 32 * rb + tok) * a.vt_ld * 4;
+#pragma unroll
+                            for (int t = 0; t < XTB; ++t) {
+                                const f32x16& c = yacc[rb][t];
+                                if (valigned[t]) {       // one 32-token group: registers (q, q + 2) are 8 consecutive positions
+#pragma unroll
+                                    for (int s2i = 0; s2i < 2; ++s2i) {
+                                        uint32_t h[4], l[4];
+                                        PrecX2::split2(c[4 * s2i + 0] + bv, c[4 * s2i + 1] + bv, h[0], l[0]);
+                                        PrecX2::split2(c[4 * s2i + 2] + bv, c[4 * s2i + 3] + bv, h[1], l[1]);
+                                        PrecX2::split2(c[4 * (s2i + 2) + 0] + bv, c[4 * (s2i + 2) + 1] + bv, h[2], l[2]);
+                                        PrecX2::split2(c[4 * (s2i + 2) + 2] + bv, c[4 * (s2i + 2) + 3] + bv, h[3], l[3]);
+                                        char* dst = rowp + PrecX2::row_byte(vcol[t][0] + 16 * s2i + 8 * hh);
+                                        *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+                                        *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int s2i = 0; s2i < 2; ++s2i) {        // half s2i of the block: tokens 16 s2i .., registers q = 2 s2i, 2 s2i + 1
+                                        if (vcol[t][s2i] < 0) continue;
+#pragma unroll
+                                        for (int e = 0; e < 2; ++e) {
+                                            const int q = 2 * s2i + e;
+                                            store4<PrecX2>(rowp + PrecX2::row_byte(vcol[t][s2i] + 8 * (2 * e + hh)),
+                                                           c[4 * q + 0] + bv, c[4 * q + 1] + bv, c[4 * q + 2] + bv, c[4 * q + 3] + bv);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if constexpr (!LAST) {
+                    // (a projection's epilogue is 24 stores in a regular tile: 2 row blocks x 3 token blocks x 4)
+                    if (KHALF == 1 && regular) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(s1[k]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, 6>{});
+    }
 }
 
 }  // namespace
@@ -337,14 +479,18 @@ hipError_t launch_ffn32x2(const Ffn32X2Args& a, hipStream_t s) {
     if (a.H != XH || a.F % HC || a.F < HC || a.F > 8192 || a.M <= 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)X_B1 + (size_t)a.F * 4;
     if (lds > 163840) return hipErrorInvalidValue;
-    static ppg::LdsLimit limit[2];
-    const bool op = a.wo_img != nullptr;
-    const void* kern = op ? reinterpret_cast<const void*>(ffn32x2_kernel<true>) : reinterpret_cast<const void*>(ffn32x2_kernel<false>);
-    const hipError_t e = limit[op].ensure(kern, lds);
-    if (e != hipSuccess) return e;
-    if (op) hipLaunchKernelGGL(ffn32x2_kernel<true>, dim3((a.M + XTOK - 1) / XTOK), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(ffn32x2_kernel<false>, dim3((a.M + XTOK - 1) / XTOK), dim3(256), lds, s, a);
-    return hipGetLastError();
+    static ppg::LdsLimit limit[3];
+    const bool op = a.wo_img != nullptr, qkv = a.wq_img != nullptr;
+    if (qkv && !op) return hipErrorInvalidValue;            // (the tail comes with the fused out-projection only)
+    auto launch = [&](auto kern, int which) {
+        const hipError_t e = limit[which].ensure(reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((a.M + XTOK - 1) / XTOK), dim3(256), lds, s, a);
+        return hipGetLastError();
+    };
+    if (qkv) return launch(ffn32x2_kernel<true, true>, 2);
+    if (op) return launch(ffn32x2_kernel<true, false>, 1);
+    return launch(ffn32x2_kernel<false, false>, 0);
 }
 
 }  // namespace ppg

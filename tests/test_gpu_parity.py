@@ -1483,7 +1483,9 @@ def test_fp16x2_feature_split_ffn_vs_token_split_and_oracle(monkeypatch):
     cases = [[1000] * 32, [1000, 997, 730, 501, 500, 499, 129, 33] * 4]
     for seed, sharpen in ((1234, 1.0), (4321, 2.0)):
         state = W.seeded_state_dict(seed=seed, sharpen=sharpen)
-        fused = E.Engine(state, 0, 'fp16x2')            # out-proj + LN1 + FFN + LN2 in one launch per layer
+        fused = E.Engine(state, 0, 'fp16x2')            # out-proj + LN1 + FFN + LN2 + the next layer's Q/K/V in one launch per layer
+        monkeypatch.setenv('PPGS_AMD_FFN32X2', '2')
+        no_tail = E.Engine(state, 0, 'fp16x2')          # ... without the Q/K/V tail
         monkeypatch.setenv('PPGS_AMD_FFN32X2', '1')
         ffn_only = E.Engine(state, 0, 'fp16x2')         # the FFN block only
         monkeypatch.setenv('PPGS_AMD_FFN32X2', '0')
@@ -1493,10 +1495,12 @@ def test_fp16x2_feature_split_ffn_vs_token_split_and_oracle(monkeypatch):
             a = fused.encode(feats.cuda(), lengths)
             b = split.encode(feats.cuda(), lengths)
             c = ffn_only.encode(feats.cuda(), lengths)
+            d = no_tail.encode(feats.cuda(), lengths)
             torch.cuda.synchronize()
             assert bool(torch.isfinite(a).all())
             assert float((a - b).abs().max()) < 2e-5, (seed, lengths[:3])
             assert float((c - b).abs().max()) < 2e-5, (seed, lengths[:3])
+            assert float((d - b).abs().max()) < 2e-5, (seed, lengths[:3])
             picks = [1, 30]
             ref = O.from_features(state, feats[picks].float(), torch.tensor([lengths[i] for i in picks])).numpy()
             assert np.abs(a[picks].cpu().numpy() - ref).max() < FP32_TOL, (seed, lengths[:3])
