@@ -154,8 +154,8 @@ def cpu_baseline(state, seconds):
     }
 
 
-def pmc_summary():
-    """The committed rocprofv3 PMC summary of THIS build: profiles/r*_pmc_summary.txt whose `# lib_sha256_16=` header
+def pmc_summary(suffix=''):
+    """The committed rocprofv3 PMC summary of THIS build: profiles/r*_pmc_summary<suffix>.txt whose `# lib_sha256_16=` header
     equals the sha256 of the library this process loaded (tests/pmc_summary.py writes it; a clean `make` reproduces
     the library byte for byte).  PMC counters cannot be read inside this process, so the figures are never of the
     run that prints them -- and a summary of another build is not quoted at all.
@@ -166,7 +166,7 @@ def pmc_summary():
     from ppgs_amd import engine as E
     sha = library_sha16(E._LIB_PATH)
     seen = []
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.txt')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_summary{suffix}.txt')), reverse=True):
         with open(path) as f:
             text = f.read()
         m = re.search(r'^# lib_sha256_16=([0-9a-f]+)', text, re.M)
@@ -363,6 +363,14 @@ def run_c2(args, rank, world, local_rank, use_dist):
                   'ms_per_step': 1e3 * x2_elapsed / args.steps, 'value': BATCH * FRAMES * args.steps / x2_elapsed,
                   'end_to_end_tflops_algorithmic': BATCH * data.flops(FRAMES) * args.steps / x2_elapsed / 1e12,
                   'max_abs_vs_fp16': float((x2_out - alt_out).abs().max())}
+        # matrix-pipe busy cycles of an fp16x2 step (three MFMAs per product) from the committed PMC pass of this build
+        # with --precision fp16x2, over 4 pipes x CUs x this leg's step time at the nominal 2.4 GHz
+        x2_pmc, x2_from = pmc_summary('_fp16x2')
+        x2_busy = pmc_mfma_busy(x2_pmc) if x2_pmc else None
+        alt_x2['mfma_busy_cycles_per_step'] = x2_busy
+        alt_x2['mfma_busy_frac'] = (x2_busy / (4.0 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+                                               * alt_x2['ms_per_step'] * 2.4e6)) if x2_busy else None
+        alt_x2['mfma_busy_from'] = x2_from
         del other
     alt_streams = None
     _, info = E.plan_windows(BATCH, FRAMES, lengths)
@@ -407,7 +415,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
     launch_cus = min(launch_workgroups, cus) if launch_workgroups else cus
     launch_peak = peak * launch_cus / cus
     layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
-    pmc, pmc_from = pmc_summary()
+    pmc, pmc_from = pmc_summary('_fp16x2' if args.precision == 'fp16x2' else '')
     traffic = pmc_traffic(pmc, 'layer32_' if layer32 else 'ffn_') if pmc else None
     mfma_busy = pmc_mfma_busy(pmc) if pmc else None
     kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '

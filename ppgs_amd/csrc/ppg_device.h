@@ -617,4 +617,5 @@ struct Ffn32X2Args {
     int vt_ld;
     const int* blk_win;
     const PpgWindow* win;
+    unsigned long long* dbg;  // PPG_FFN_TIMING builds: s_memtime stamps of workgroup 0
 };

@@ -345,9 +345,13 @@ struct PpgEngine {
                     for (int k = 1; k < 15; ++k) if (t[k]) fprintf(stderr, " [%d] %llu", k, t[k] - t[0]);
                     fprintf(stderr, "\n");
                 }
-                if (layer32) {
+                if (layer32 || split) {
                     for (int w = 0; w < 4; ++w) {
                         const unsigned long long* t = h + w * 8;
+                        if (split)
+                            fprintf(stderr, "ffn32x2 wave %d chunk 4: A1 %llu  wait %llu  A2 %llu  hand-over + barrier + wait %llu  B1 %llu  B2 (+ wait) %llu | total %llu\n",
+                                    w, t[1] - t[0], t[6] - t[1], t[7] - t[6], t[2] - t[7], t[3] - t[2], t[5] - t[3], t[5] - t[0]);
+                        else
                         fprintf(stderr, "layer32 wave %d chunk 4 (hidden 256: one stream): A blocks 0-2 %llu  A blocks 3,4 + h writes %llu  B blocks 0-2 + h writes %llu  B blocks 3,4 %llu | total %llu\n",
                                 w, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[5] - t[3], t[5] - t[0]);
                     }
@@ -1405,6 +1409,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
                 a.xb = Xb; a.X = X; a.xb_out = Xb; a.w1_img = d.w1x_img; a.w2_img = d.w2x_img;
                 a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2; a.M = M; a.F = F; a.H = H;
                 if (e->ffn32x2 >= 2) { a.ao = ao; a.wo_img = d.wox_img; a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; }
+                a.dbg = l == 0 ? e->ffn_dbg : nullptr;
                 qkv_done = e->ffn32x2 >= 3 && l + 1 < c.num_layers;
                 if (qkv_done) {
                     const DevLayer& nx = e->layers[l + 1];

@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* stats = reinterpret_cast<float*>(smem + X_STATS);
     const int fbase = 64 * wave;
 
+#ifdef PPG_FFN_TIMING
+    auto pstamp = [&](int k) { if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[128 + wave * 16 + k] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto pstamp = [&](int) {};
+#endif
+    pstamp(0);
     u32x4 s1[16], s2[16];
     auto load16 = [&](u32x4 (&wf)[16], const char* base) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
@@ -213,8 +219,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }(), ...);
         }(std::integer_sequence<int, 0, 1>{});
+        pstamp(1);
         // x1: stays in the accumulators (the FFN sums on top of its own residual) and goes into the panel
         layer_norm(std::true_type{}, lnp1, [&](int t, int rb, int, const f32x16& y) { panel_write(t, rb, y); });
+        pstamp(2);
         load16(s1, w1_of(0));
         vm_wait_all(s1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -232,7 +240,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int t = 0; t < XTB; ++t) yacc[rb][t] = zero;
     }
 
+    pstamp(3);
     for (int c = 0; c < NCH; ++c) {
+#ifdef PPG_FFN_TIMING
+        auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
+#else
+        auto cstamp = [&](int) {};
+#endif
+        cstamp(0);
         f32x16 bias;            // C operand of the chunk's first MFMAs: b1 of the lane's 16 hidden rows
         {
             u32x4 braw[4];
@@ -259,7 +274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else hacc[tb] = P::mma32(s1[ks], bf, hacc[tb]);
             if constexpr (i % 6 == 1) gload_frag<16 + i / 6>(s2[i / 6], voff, w1c);
         });
+        cstamp(1);
         vm_wait_all(s2);
+        cstamp(6);
         // A2: W1lo x x_hi
         stream<OffA2, 16 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hacc[tb] = P::mma32(s2[ks], bf, hacc[tb]);
             if constexpr (i % 3 == 1) gload_frag<i / 3>(s1[i / 3], voff, w2c);
         });
+        cstamp(7);
         // h = relu(hacc), split: registers 8 s2 .. + 7 of block t are K-step 2 wave + s2 of the chunk's h
 #pragma unroll
         for (int t = 0; t < XTB; ++t)
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         vm_wait_all(s1);
+        cstamp(2);
         // B1: W2hi x {h_hi, h_lo}
         stream<OffB1, 8 * 6, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
@@ -294,6 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             yacc[1][tb] = P::mma32(s1[8 + ks], bf, yacc[1][tb]);
             if constexpr (i < 16) gload_frag<16 + i>(s2[i], voff, w2c);
         });
+        cstamp(3);
         vm_wait_all(s2);
         // B2: W2lo x h_hi
         stream<OffB2, 8 * 3, 6>(hb0, hb0, [&](auto ic, const u32x4& bf) {
@@ -303,8 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             yacc[1][tb] = P::mma32(s2[8 + ks], bf, yacc[1][tb]);
             if constexpr (i < 16) gload_frag<i>(s1[i], voff, next1);
         });
+        cstamp(5);
     }
     vm_wait_all(s1);
+    pstamp(4);
 
     // ---- + b2 (+ the residual row, unless the accumulators started from it), LayerNorm-2, fp32 rows and the operand copy out
     auto store = [&](int t, int rb, int m, const f32x16& y) {
@@ -330,6 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (OP) layer_norm(std::false_type{}, lnp, store);
     else layer_norm(std::true_type{}, lnp, store);
 
+    pstamp(5);
     if constexpr (QKV) {
         // ---- the next layer's Q / K / V from the x2 panel: three projections of 288 MFMAs per wave, image order
         // [wave][kind][K half][hi (rb, ks8) | lo (rb, ks8)].  Q and K leave as [32 hi | 32 lo] rows (a lane owns 16
@@ -339,6 +362,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // fragment order), both planes.
         const char* wq = a.wq_img + ((size_t)wave * 3 * 64) * 1024;
         load16(s1, wq);
+        // the in_proj bias -> LDS (the h region: every wave is past its last chunk, LayerNorm-2's barrier lies between)
+        float* bql = reinterpret_cast<float*>(smem + X_H);
+        if (tid < 3 * XH / 4) reinterpret_cast<float4*>(bql)[tid] = reinterpret_cast<const float4*>(a.bq)[tid];
         // transposed-V columns of the 16-token halves of every token block (as ppg_layer32.h qkv_tail)
         int vcol[XTB][2];
         bool valigned[XTB];
@@ -362,110 +388,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         vm_wait_all(s1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                     // the panel holds x2
+        __syncthreads();                                     // the panel holds x2, the bias is in LDS
         // Stage = (projection, K half).  Its hi fragments are in set 1; the lo fragments travel into set 2 under the
-        // stage's first stream, the NEXT stage's hi fragments into set 1 under its second.  A projection's epilogue --
-        // bias, split, stores -- is issued behind those requests; vmcnt counts in order, so the wait for the fragments
-        // is vmcnt(stores of the epilogue) in a regular tile, not a wait for the stores' acknowledgement.
+        // stage's first stream, the NEXT stage's hi fragments into set 1 under its second.  The projections alternate
+        // between two accumulator sets: the epilogue of projection k -- bias, split, 24 stores of 16 bytes per lane --
+        // rides between the MFMAs of projection k + 1's first stream, behind that stream's 16 fragment requests, so
+        // that the wait for them is vmcnt(24) in a regular tile (vmcnt counts in order), not a wait for the stores'
+        // acknowledgement: a CU retires ~10 bytes of stores per clock, 96 KiB per projection and workgroup -- as long
+        // as the projection's MFMAs take (PPG_FFN_TIMING stamps: 85 k cycles for the tail with the epilogues exposed).
+        f32x16 qacc[2][2][XTB];
+        float4 b4[2][4];
+        float bvv[2];
+        auto bias_load = [&](auto kind_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            if constexpr (KIND < 2) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b4[rb][q] = *reinterpret_cast<const float4*>(bql + XH * KIND + fbase + 32 * rb + 16 * hh + 4 * q);
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) bvv[rb] = bql[2 * XH + pair_row(fbase + 32 * rb + tok)];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                asm volatile("" : "+v"(bvv[rb]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(b4[rb][q].x), "+v"(b4[rb][q].y), "+v"(b4[rb][q].z), "+v"(b4[rb][q].w));
+            }
+        };
+        // epilogue unit U = (row block U / 3, token block U % 3) of projection KIND: 4 stores in a regular tile
+        auto unit = [&](auto kind_tag, auto u_tag) {
+            constexpr int KIND = decltype(kind_tag)::value, U = decltype(u_tag)::value, rb = U / 3, t = U % 3;
+            const f32x16& c = qacc[KIND & 1][rb][t];
+            if constexpr (KIND < 2) {
+                const int m = m0 + 32 * t + tok;
+                if (m >= a.M) return;
+                const float y[16] = {c[0] + b4[rb][0].x, c[1] + b4[rb][0].y, c[2] + b4[rb][0].z, c[3] + b4[rb][0].w, c[4] + b4[rb][1].x, c[5] + b4[rb][1].y, c[6] + b4[rb][1].z, c[7] + b4[rb][1].w,
+                                     c[8] + b4[rb][2].x, c[9] + b4[rb][2].y, c[10] + b4[rb][2].z, c[11] + b4[rb][2].w, c[12] + b4[rb][3].x, c[13] + b4[rb][3].y, c[14] + b4[rb][3].z, c[15] + b4[rb][3].w};
+                char* dst = a.qk_out + (size_t)m * (2 * XH * 4) + KIND * (XH * 4) + (2 * wave + rb) * 128 + hh * 32;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    u32x4 fh, fl;
+                    uint32_t* ph = reinterpret_cast<uint32_t*>(&fh);
+                    uint32_t* pl = reinterpret_cast<uint32_t*>(&fl);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) PrecX2::split2(y[8 * s + 2 * j], y[8 * s + 2 * j + 1], ph[j], pl[j]);
+                    *reinterpret_cast<u32x4*>(dst + 16 * s) = fh;
+                    *reinterpret_cast<u32x4*>(dst + 64 + 16 * s) = fl;
+                }
+            } else {
+                // lane = V^T row fbase + 32 rb + tok, registers 4 q + r = token 8 q + 4 hh + r of the block
+                const float bv = bvv[rb];
+                char* rowp = a.vt_out + (size_t)(fbase + 32 * rb + tok) * a.vt_ld * 4;
+                if (valigned[t]) {       // one 32-token group: registers (q, q + 2) are 8 consecutive positions
+#pragma unroll
+                    for (int s2i = 0; s2i < 2; ++s2i) {
+                        uint32_t h[4], l[4];
+                        PrecX2::split2(c[4 * s2i + 0] + bv, c[4 * s2i + 1] + bv, h[0], l[0]);
+                        PrecX2::split2(c[4 * s2i + 2] + bv, c[4 * s2i + 3] + bv, h[1], l[1]);
+                        PrecX2::split2(c[4 * (s2i + 2) + 0] + bv, c[4 * (s2i + 2) + 1] + bv, h[2], l[2]);
+                        PrecX2::split2(c[4 * (s2i + 2) + 2] + bv, c[4 * (s2i + 2) + 3] + bv, h[3], l[3]);
+                        char* dst = rowp + PrecX2::row_byte(vcol[t][0] + 16 * s2i + 8 * hh);
+                        *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+                        *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+                    }
+                } else {
+#pragma unroll
+                    for (int s2i = 0; s2i < 2; ++s2i) {        // half s2i of the block: tokens 16 s2i .., registers q = 2 s2i, 2 s2i + 1
+                        if (vcol[t][s2i] < 0) continue;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int q = 2 * s2i + e;
+                            store4<PrecX2>(rowp + PrecX2::row_byte(vcol[t][s2i] + 8 * (2 * e + hh)),
+                                           c[4 * q + 0] + bv, c[4 * q + 1] + bv, c[4 * q + 2] + bv, c[4 * q + 3] + bv);
+                        }
+                    }
+                }
+            }
+        };
         [&]<int... STAGE>(std::integer_sequence<int, STAGE...>) {
             ([&] {
                 constexpr int KIND = STAGE / 2, KHALF = STAGE % 2;
                 constexpr bool SWAP = KIND == 2;
                 constexpr bool LAST = STAGE == 5;
+                constexpr bool EPI = KHALF == 0 && KIND > 0;         // the previous projection's epilogue rides along
+                f32x16 (&acc)[2][XTB] = qacc[KIND & 1];
                 const char* lo = wq + (size_t)(STAGE * 32 + 16) * 1024;
                 const char* nxt = wq + (size_t)((LAST ? STAGE : STAGE + 1) * 32) * 1024;
+                if constexpr (EPI) bias_load(std::integral_constant<int, KIND - 1>{});
                 stream<OffO1<KHALF>, 8 * 6, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int ks = i / 6, tb = i % 3;
                     if constexpr (KHALF == 0 && i < 3) {
-                        yacc[0][tb] = SWAP ? P::mma32(bf, s1[0], zero) : P::mma32(s1[0], bf, zero);
-                        yacc[1][tb] = SWAP ? P::mma32(bf, s1[8], zero) : P::mma32(s1[8], bf, zero);
+                        acc[0][tb] = SWAP ? P::mma32(bf, s1[0], zero) : P::mma32(s1[0], bf, zero);
+                        acc[1][tb] = SWAP ? P::mma32(bf, s1[8], zero) : P::mma32(s1[8], bf, zero);
                     } else {
-                        yacc[0][tb] = SWAP ? P::mma32(bf, s1[ks], yacc[0][tb]) : P::mma32(s1[ks], bf, yacc[0][tb]);
-                        yacc[1][tb] = SWAP ? P::mma32(bf, s1[8 + ks], yacc[1][tb]) : P::mma32(s1[8 + ks], bf, yacc[1][tb]);
+                        acc[0][tb] = SWAP ? P::mma32(bf, s1[ks], acc[0][tb]) : P::mma32(s1[ks], bf, acc[0][tb]);
+                        acc[1][tb] = SWAP ? P::mma32(bf, s1[8 + ks], acc[1][tb]) : P::mma32(s1[8 + ks], bf, acc[1][tb]);
                     }
                     if constexpr (i < 16) gload_frag<i>(s2[i], voff, lo);
+                    if constexpr (EPI && i >= 16 && (i - 16) % 5 == 0 && (i - 16) / 5 < 6)
+                        unit(std::integral_constant<int, KIND - 1>{}, std::integral_constant<int, (i - 16) / 5>{});
                 });
-                vm_wait_all(s2);
+                if constexpr (STAGE == 2) pstamp(13);
+                if (EPI && regular) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (STAGE == 2) pstamp(14);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(s2[k]));
+                __builtin_amdgcn_sched_barrier(0);
                 stream<OffO2<KHALF>, 8 * 3, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int ks = i / 3, tb = i % 3;
-                    yacc[0][tb] = SWAP ? P::mma32(bf, s2[ks], yacc[0][tb]) : P::mma32(s2[ks], bf, yacc[0][tb]);
-                    yacc[1][tb] = SWAP ? P::mma32(bf, s2[8 + ks], yacc[1][tb]) : P::mma32(s2[8 + ks], bf, yacc[1][tb]);
+                    acc[0][tb] = SWAP ? P::mma32(bf, s2[ks], acc[0][tb]) : P::mma32(s2[ks], bf, acc[0][tb]);
+                    acc[1][tb] = SWAP ? P::mma32(bf, s2[8 + ks], acc[1][tb]) : P::mma32(s2[8 + ks], bf, acc[1][tb]);
                     if constexpr (!LAST && i < 16) gload_frag<i>(s1[i], voff, nxt);
                 });
-                if constexpr (KHALF == 1) {
-                    // epilogue of projection KIND (its stores queue behind the next stage's fragment requests)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        if constexpr (KIND < 2) {
-                            float4 b4[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(a.bq + XH * KIND + fbase + 32 * rb + 16 * hh + 4 * q);
-#pragma unroll
-                            for (int t = 0; t < XTB; ++t) {
-                                const int m = m0 + 32 * t + tok;
-                                if (m >= a.M) continue;
-                                const f32x16& c = yacc[rb][t];
-                                const float y[16] = {c[0] + b4[0].x, c[1] + b4[0].y, c[2] + b4[0].z, c[3] + b4[0].w, c[4] + b4[1].x, c[5] + b4[1].y, c[6] + b4[1].z, c[7] + b4[1].w,
-                                                     c[8] + b4[2].x, c[9] + b4[2].y, c[10] + b4[2].z, c[11] + b4[2].w, c[12] + b4[3].x, c[13] + b4[3].y, c[14] + b4[3].z, c[15] + b4[3].w};
-                                char* dst = a.qk_out + (size_t)m * (2 * XH * 4) + KIND * (XH * 4) + (2 * wave + rb) * 128 + hh * 32;
-#pragma unroll
-                                for (int s = 0; s < 2; ++s) {
-                                    u32x4 fh, fl;
-                                    uint32_t* ph = reinterpret_cast<uint32_t*>(&fh);
-                                    uint32_t* pl = reinterpret_cast<uint32_t*>(&fl);
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) PrecX2::split2(y[8 * s + 2 * j], y[8 * s + 2 * j + 1], ph[j], pl[j]);
-                                    *reinterpret_cast<u32x4*>(dst + 16 * s) = fh;
-                                    *reinterpret_cast<u32x4*>(dst + 64 + 16 * s) = fl;
-                                }
-                            }
-                        } else {
-                            // lane = V^T row fbase + 32 rb + tok, registers 4 q + r = token 8 q + 4 hh + r of the block
-                            const float bv = a.bq[2 * XH + pair_row(fbase + 32 * rb + tok)];
-                            char* rowp = a.vt_out + (size_t)(fbase + 32 * rb + tok) * a.vt_ld * 4;
-#pragma unroll
-                            for (int t = 0; t < XTB; ++t) {
-                                const f32x16& c = yacc[rb][t];
-                                if (valigned[t]) {       // one 32-token group: registers (q, q + 2) are 8 consecutive positions
-#pragma unroll
-                                    for (int s2i = 0; s2i < 2; ++s2i) {
-                                        uint32_t h[4], l[4];
-                                        PrecX2::split2(c[4 * s2i + 0] + bv, c[4 * s2i + 1] + bv, h[0], l[0]);
-                                        PrecX2::split2(c[4 * s2i + 2] + bv, c[4 * s2i + 3] + bv, h[1], l[1]);
-                                        PrecX2::split2(c[4 * (s2i + 2) + 0] + bv, c[4 * (s2i + 2) + 1] + bv, h[2], l[2]);
-                                        PrecX2::split2(c[4 * (s2i + 2) + 2] + bv, c[4 * (s2i + 2) + 3] + bv, h[3], l[3]);
-                                        char* dst = rowp + PrecX2::row_byte(vcol[t][0] + 16 * s2i + 8 * hh);
-                                        *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
-                                        *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int s2i = 0; s2i < 2; ++s2i) {        // half s2i of the block: tokens 16 s2i .., registers q = 2 s2i, 2 s2i + 1
-                                        if (vcol[t][s2i] < 0) continue;
-#pragma unroll
-                                        for (int e = 0; e < 2; ++e) {
-                                            const int q = 2 * s2i + e;
-                                            store4<PrecX2>(rowp + PrecX2::row_byte(vcol[t][s2i] + 8 * (2 * e + hh)),
-                                                           c[4 * q + 0] + bv, c[4 * q + 1] + bv, c[4 * q + 2] + bv, c[4 * q + 3] + bv);
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                if constexpr (!LAST) {
-                    // (a projection's epilogue is 24 stores in a regular tile: 2 row blocks x 3 token blocks x 4)
-                    if (KHALF == 1 && regular) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(s1[k]));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if constexpr (!LAST) vm_wait_all(s1);
+                pstamp(7 + STAGE);
             }(), ...);
         }(std::make_integer_sequence<int, 6>{});
+        // the last projection's epilogue
+        bias_load(std::integral_constant<int, 2>{});
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            (unit(std::integral_constant<int, 2>{}, std::integral_constant<int, U>{}), ...);
+        }(std::make_integer_sequence<int, 6>{});
+        pstamp(6);
     }
 }
 

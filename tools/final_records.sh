@@ -15,6 +15,13 @@ timeout 300 python bench.py --precision fp32 --no-alt --no-cpu --steps 20 --warm
 timeout 900 bash tests/prof.sh $tag > $out/prof.log 2>&1
 python tests/pmc_summary.py gpurun_out/prof_$tag/pmc*/bench_counter_collection.csv > $out/${tag}_pmc_summary.txt 2>$out/pmc_summary.err
 find gpurun_out/prof_$tag/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats.csv
+# the fp16x2 mode: kernel stats and the matrix-pipe counters of its step
+( cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_x2/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision fp16x2 --no-cpu --no-alt --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/prof_x2.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_x2/pmc1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision fp16x2 --no-cpu --no-alt --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/$out/prof_x2_pmc.log 2>&1 )
+python tests/pmc_summary.py gpurun_out/prof_${tag}_x2/pmc1/bench_counter_collection.csv > $out/${tag}_pmc_summary_fp16x2.txt 2>>$out/pmc_summary.err
+find gpurun_out/prof_${tag}_x2/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats_fp16x2.csv
+timeout 300 python bench.py --precision fp16x2 --no-alt --no-cpu --steps 20 --warmup 5 > $out/bench_x2.log 2>&1; grep "^{" $out/bench_x2.log | tail -1 > $out/${tag}_bench_fp16x2.json
 # one pipeline under the profiler: the per-kernel whole-chip figures
 ( cd /tmp && export TMPDIR=/tmp && PPGS_AMD_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_one/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-alt --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/prof_one.log 2>&1 )
 find gpurun_out/prof_${tag}_one/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_one_pipeline_kernel_stats.csv
