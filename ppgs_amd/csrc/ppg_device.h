@@ -594,6 +594,11 @@ struct Gemm32Args {
     // item b owns rows b * rows_per_item .., valid frames in win[b].valid; null: every row is kept
     const PpgWindow* win;
     int rows_per_item;
+    // Q | K | V (vt != null): passes (of 256 features) below v_pass0 go to out16 rows of leading dimension ld_out, the
+    // others to V^T [N - 256 v_pass0][vt_ld] in attn_kernel's layout (image rows of those passes in pair_row order);
+    // items start at multiples of 32 rows (rows_per_item % 32 == 0)
+    char* vt;
+    int vt_ld, ld_out, v_pass0;
 };
 
 // ppg_ffn32x2.hip: the FFN block in the fp16x2 mode on the feature-split machinery (96-token workgroups)

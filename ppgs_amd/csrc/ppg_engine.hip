@@ -2000,13 +2000,16 @@ struct PpgW2v2Body {
     char* pos_w = nullptr; float* pos_b = nullptr;
     float* en_g = nullptr; float* en_b = nullptr;
     struct Layer { char* wqkv; float* bqkv; char* wo; float* bo; float* g1; float* e1; char* w1; float* b1; char* w2; float* b2; float* g2; float* e2;
-                   char* wo_img; char* w1_img; char* w2_img; };   // fragment images for ppg_gemm32.hip (16-bit modes)
+                   char* wo_img; char* w1_img; char* w2_img; char* wqkv_img; };   // fragment images for ppg_gemm32.hip (16-bit modes)
     bool gemm32 = true;            // PPGS_AMD_W2V2_GEMM32=0: linear_kernel<EPI_GENERAL> for every projection
+    bool qkv32 = true;             // PPGS_AMD_W2V2_QKV32=0: Q/K/V on linear_kernel<EPI_QKV>
     std::vector<Layer> layer;
     // per pipeline (a batch of >= 8 items runs as two half-batches on two HIP streams, as the PPG network's engine does)
     struct Slot { char* staging = nullptr; size_t staging_bytes = 0; hipEvent_t uploaded = nullptr; };   // pinned tables of the call in flight
     Slot slot[2];
     int pipelines = 2;             // PPGS_AMD_W2V2_STREAMS
+    int ablate = 0;                // PPGS_AMD_W2V2_ABLATE (timing experiments, wrong results): 1 no GELU in FFN-1, 2 no LayerNorm launches,
+                                   // 4 no attention, 8 no Q/K/V, 16 no out-proj, 32 no FFN-1, 64 no FFN-2
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~PpgW2v2Body() {
@@ -2045,6 +2048,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     m->hidden = H; m->heads = w->heads; m->ffn = F; m->layers = L; m->taps = w->conv_kernel; m->groups = w->conv_groups;
     m->eps = w->layer_norm_eps;
     if (const char* v = getenv("PPGS_AMD_W2V2_GEMM32")) m->gemm32 = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_W2V2_QKV32")) m->qkv32 = atoi(v) != 0;
     if (E->sz != 2 || H % 256 || F % 256 || H % 128 || F % 128) m->gemm32 = false;
     const int CG = H / w->conv_groups;                       // 48 channels per group
     m->gpt = (CG * E->sz + 63) / 64;                         // K-groups of 64 bytes per tap: 2 (16-bit, padded) or 3 (fp32)
@@ -2114,8 +2118,22 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
         if ((rc = upload_f32(E, lw.ffn2_bias, H, 0, &d.b2))) return rc;
         if ((rc = upload_f32(E, lw.norm2_weight, H, 0, &d.g2))) return rc;
         if ((rc = upload_f32(E, lw.norm2_bias, H, 0, &d.e2))) return rc;
-        d.wo_img = d.w1_img = d.w2_img = nullptr;
+        d.wo_img = d.w1_img = d.w2_img = d.wqkv_img = nullptr;
         if (m->gemm32) {
+            // Q | K | V as one image of 3H / 256 passes: Q (scaled as above) and K rows in accumulator order phi, the V
+            // passes' rows in pair_row order (their accumulators come out transposed: ppg_gemm32.hip mode 3)
+            const int chunks = H / 128, frags = (3 * H / 256) * 4 * chunks * 16;
+            rc = upload_matrix(E, frags * 64, 8, frags * 64, 8,
+                               [&](int r, int j) {
+                                   const int f = r >> 6, ln = r & 63;
+                                   const int ks = f & 7, rb = (f >> 3) & 1, c = (f >> 4) % chunks, wv = ((f >> 4) / chunks) & 3, p = (f >> 4) / chunks / 4;
+                                   const int k = 128 * c + 16 * ks + 8 * (ln >> 5) + j;
+                                   const int vp0 = 2 * H / 256;
+                                   if (p >= vp0) return lw.v_weight[(size_t)pair_row(256 * (p - vp0) + 64 * wv + 32 * rb + (ln & 31)) * H + k];
+                                   const int n = 256 * p + 64 * wv + 32 * rb + phi(ln & 31);
+                                   return n < H ? lw.q_weight[(size_t)n * H + k] * qscale : lw.k_weight[(size_t)(n - H) * H + k];
+                               }, &d.wqkv_img);
+            if (rc) return rc;
             if ((rc = image(lw.out_weight, H, H, &d.wo_img))) return rc;
             if ((rc = image(lw.ffn1_weight, F, H, &d.w1_img))) return rc;
             if ((rc = image(lw.ffn2_weight, H, F, &d.w2_img))) return rc;
@@ -2127,6 +2145,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (const char* v = getenv("PPGS_AMD_W2V2_STREAMS")) m->pipelines = std::max(1, std::min(atoi(v), 2));
+    if (const char* v = getenv("PPGS_AMD_W2V2_ABLATE")) m->ablate = atoi(v);
     *out = m.release();
     return PPG_OK;
 }
@@ -2272,7 +2291,9 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         a.W = W; a.bias = bias; a.N = N; a.out_ld32 = H;
         return a;
     };
+    const int abl = m->ablate;
     auto layer_norm = [&](const float* g, const float* b) {
+        if (abl & 2) return hipSuccess;
         return ppg::launch_w2v2_layernorm(prec, H, P, nullptr, g, b, M, M, M, m->eps, X, xb_out, s);
     };
     // feature projection: LayerNorm(512) -> Linear, rows past the valid frames zeroed (HF: hidden_states[~mask] = 0)
@@ -2301,9 +2322,17 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         {
             LinearArgs a = general(act_x, H, d.wqkv, d.bqkv, 3 * H);
             a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = vt_ld; a.v_start = 2 * H;
-            LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, nt, a, 3 * H / 256, s), "w2v2 qkv");
+            if (abl & 8) {
+            } else if (m->gemm32 && m->qkv32) {
+                Gemm32Args g{};
+                g.x = Xb; g.w_img = d.wqkv_img; g.bias = d.bqkv; g.out16 = qk; g.M = M; g.N = 3 * H; g.K = H;
+                g.vt = vt; g.vt_ld = vt_ld; g.ld_out = 2 * H; g.v_pass0 = 2 * H / 256; g.rows_per_item = R;
+                LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 qkv");
+            } else {
+                LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, nt, a, 3 * H / 256, s), "w2v2 qkv");
+            }
         }
-        {
+        if (!(abl & 4)) {
             AttnArgs a{};
             a.qk = qk; a.qk_ld_bytes = 2 * H * sz; a.vt = vt; a.vt_ld_bytes = vt_ld * sz;
             a.ao = ao; a.H = H; a.causal = 0;
@@ -2313,14 +2342,14 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         if (m->gemm32) {
             Gemm32Args g{};
             g.x = ao; g.w_img = d.wo_img; g.bias = d.bo; g.residual = X; g.out32 = P; g.M = M; g.N = H; g.K = H;
-            LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 out-proj");
+            if (!(abl & 16)) LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 out-proj");
             LAUNCH_OK(layer_norm(d.g1, d.e1), "w2v2 LayerNorm 1");
             Gemm32Args f1{};
-            f1.x = Xb; f1.w_img = d.w1_img; f1.bias = d.b1; f1.out16 = hid; f1.M = M; f1.N = F; f1.K = H; f1.act_fn = 2;
-            LAUNCH_OK(ppg::launch_gemm32(prec, f1, s), "w2v2 ffn 1");
+            f1.x = Xb; f1.w_img = d.w1_img; f1.bias = d.b1; f1.out16 = hid; f1.M = M; f1.N = F; f1.K = H; f1.act_fn = (abl & 1) ? 0 : 2;
+            if (!(abl & 32)) LAUNCH_OK(ppg::launch_gemm32(prec, f1, s), "w2v2 ffn 1");
             Gemm32Args f2{};
             f2.x = hid; f2.w_img = d.w2_img; f2.bias = d.b2; f2.residual = X; f2.out32 = P; f2.M = M; f2.N = H; f2.K = F;
-            LAUNCH_OK(ppg::launch_gemm32(prec, f2, s), "w2v2 ffn 2");
+            if (!(abl & 64)) LAUNCH_OK(ppg::launch_gemm32(prec, f2, s), "w2v2 ffn 2");
             LAUNCH_OK(layer_norm(d.g2, d.e2), "w2v2 LayerNorm 2");
             continue;
         }

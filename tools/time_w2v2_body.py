@@ -10,12 +10,13 @@ transformers.utils.logging.set_verbosity_error()
 torch.manual_seed(5)
 model = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config()).eval().cuda()
 body = E.W2v2Body(model, 0, sys.argv[1] if len(sys.argv) > 1 else 'bf16')
-x = torch.randn(16, 499, 512).cuda()
+B = int(os.environ.get("BODY_BATCH", 16))
+x = torch.randn(B, 499, 512).cuda()
 for _ in range(5):
-    body(x, [499] * 16)
+    body(x, [499] * B)
 torch.cuda.synchronize()
 start = time.perf_counter()
 for _ in range(20):
-    body(x, [499] * 16)
+    body(x, [499] * B)
 torch.cuda.synchronize()
 print(f'{(time.perf_counter() - start) / 20 * 1e3:.3f} ms')
