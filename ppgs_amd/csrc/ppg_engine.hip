@@ -2314,7 +2314,11 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         LinearArgs a = general(act_x, H, m->pos_w, m->pos_b, H);
         a.taps = m->taps; a.groups_per_tap = m->gpt; a.real_groups = a.total_groups = m->taps * m->gpt;
         a.act_y_stride = (H / m->groups) * sz; a.act_fn = 2; a.residual = X; a.out32 = P;
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 3, 1, a, m->groups, s), "w2v2 positional convolution");
+        // (32 or 48 tokens per wave -- fewer re-reads of a group's 590 KB of weights -- measured: no faster, 3.20 / 3.24
+        // against 3.23 ms per forward: the launch is bound by the re-reads of the ACTIVATION rows, one pass per tap)
+        int pos_nt = 1;
+        if (const char* v = getenv("PPGS_AMD_W2V2_POS_NT")) pos_nt = std::max(1, std::min(atoi(v), sz == 2 ? 3 : 2));
+        LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 3, pos_nt, a, m->groups, s), "w2v2 positional convolution");
         LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
     }
     for (int l = 0; l < m->layers; ++l) {

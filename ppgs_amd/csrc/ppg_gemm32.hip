@@ -1,15 +1,21 @@
-// Feature-split GEMM for the wide projections of the wav2vec 2.0 body (HF Wav2Vec2EncoderLayer: attention.out_proj,
-// feed_forward.intermediate_dense / output_dense):
+// Feature-split GEMM for the projections of the wav2vec 2.0 body (HF Wav2Vec2EncoderLayer: attention q / k / v /
+// out_proj, feed_forward.intermediate_dense / output_dense, the feature projection):
 //     Y[m][n] = act_fn(sum_k X[m][k] W[n][k] + bias[n]) [+ R[m][n]]      X row-major 16-bit, W as A-fragment images
-// on v_mfma_f32_32x32x16, the machinery of ppg_layer32.hip / ppg_head32.hip: one workgroup = 160 token rows x 256
-// output features, wave w owns features 64 w .. + 63 (two row blocks), weights go from host-packed fragment images
-// straight into registers (two sets of 16 fragments = one K chunk of 128 each, alternating: the next chunk's travel
-// under this chunk's MFMAs), activations are B fragments read from a token-major LDS tile (rows of 272 bytes = 17 x
-// 16: the 32 rows of a fragment read fall into 16 different 16-byte bank groups).  Three tile buffers: the rows of
-// chunk c + 2 are requested (plain global loads, 32 - 40 registers per lane) at the end of chunk c's MFMA stream and
-// written to LDS at the start of chunk c + 1 -- a whole stream to land in; one barrier per chunk.  linear_kernel, which this replaces for these GEMMs,
-// stages the WEIGHTS through LDS by DMA (60 cycles per KiB on the issuing wave) and re-reads the activations from
-// global memory per K group.
+// on v_mfma_f32_32x32x16, the machinery of ppg_layer32.hip / ppg_head32.hip: one workgroup = 128 or 160 token rows x
+// 256 output features, wave w owns features 64 w .. + 63 (two row blocks), weights go from host-packed fragment
+// images straight into registers (three sets of 16 fragments = one K chunk of 128 each: chunk c + 2's travel under
+// chunks c and c + 1), activations are B fragments read from a token-major LDS tile (rows of 272 bytes = 17 x 16: the
+// 32 rows of a fragment read fall into 16 different 16-byte bank groups), three tile buffers.  The K loop is ONE
+// stream of LDS fragment reads that runs on across the chunks (a ring of 8 in flight), with the chunk's requests,
+// the tile writes of the next chunk and the chunk's one barrier riding in its steps (see `chunk` below).
+// Measured per workgroup at 16 x 499 frames (PPG_GEMM_TIMING stamps, cycles): prologue 5 - 7 k, a chunk 2.8 - 3.1 k
+// (64 MFMAs per wave = 2.05 k; 2.45 k with the weights hot in L2; the requests' issue slots are the rest),
+// epilogue 8 k (Q / K), 14 k (residual: the 25 MB of residual rows all workgroups read at once), 15 k (GELU: VALU).
+// Two things that cost more than the arithmetic before they were found: (1) stores from the ACCUMULATOR layout
+// (a lane owns 16 features of ONE token: 64 rows per instruction) -- the epilogue turns the block through LDS into
+// row order; (2) the compiler's wait-count insertion across the `m < M` control flow around the stores (a
+// vmcnt(0) per row group = the previous store's acknowledgement, 300 cycles per store instruction:
+// tools/wait_scan.py audits the built library for the pattern).
 #include "ppg_layer32.h"
 #include <cstdio>
 #include <map>
@@ -147,11 +153,7 @@ __device__ __forceinline__ void gemm32_body(const Gemm32Args& a, char* smem) {
                 acc[1][tb] = SWAP ? P::mma32(bf, cur[8 + ks], acc[1][tb]) : P::mma32(cur[8 + ks], bf, acc[1][tb]);
             }
             static_assert(STEPS >= 16 + NST + RD, "requests and writes before the barrier step");
-#ifndef GEMM_ABL
-#define GEMM_ABL 0
-#endif
-            if constexpr (GEMM_ABL & 1) {
-            } else if constexpr (I < 8) {
+            if constexpr (I < 8) {
                 load_frag.template operator()<I, TO_ACC>(nxt2, nbase);
             } else if constexpr (I < 8 + NST) {
                 constexpr int k = I - 8;
@@ -165,7 +167,7 @@ __device__ __forceinline__ void gemm32_body(const Gemm32Args& a, char* smem) {
             } else if constexpr (I < 16 + NST) {
                 load_frag.template operator()<I - NST, TO_ACC>(nxt2, nbase);
             }
-            if constexpr (I == STEPS - RD && !(GEMM_ABL & 2)) __builtin_amdgcn_s_barrier();
+            if constexpr (I == STEPS - RD) __builtin_amdgcn_s_barrier();
             if constexpr (I + RD < STEPS) ds_read128<OffTile<GT>::at(I + RD)>(bf, tile);
             else ds_read128<OffTile<GT>::at(I + RD - STEPS)>(bf, tile_next);
         };
@@ -277,25 +279,31 @@ __device__ __forceinline__ void gemm32_body(const Gemm32Args& a, char* smem) {
 #ifdef PPG_GEMM_TIMING
         if (t == 1) GSTAMP(14);
 #endif
+        // (all arithmetic of the block first, in straight-line code: the row groups' dependent chains -- the GELU
+        // polynomial -- interleave; the stores' `m < M` control flow comes behind)
+        float y[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             asm volatile("" : "+v"(rows[i]));
-            const int m = m0 + 32 * t + 4 * i + r4;
-            float y[4] = {__uint_as_float(rows[i][0]) + bias4.x, __uint_as_float(rows[i][1]) + bias4.y,
-                          __uint_as_float(rows[i][2]) + bias4.z, __uint_as_float(rows[i][3]) + bias4.w};
+            y[i][0] = __uint_as_float(rows[i][0]) + bias4.x; y[i][1] = __uint_as_float(rows[i][1]) + bias4.y;
+            y[i][2] = __uint_as_float(rows[i][2]) + bias4.z; y[i][3] = __uint_as_float(rows[i][3]) + bias4.w;
             if constexpr (GELU) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = gelu_erf(y[k]);
+                const f32x2 lo = gelu_erf_pair(f32x2{y[i][0], y[i][1]}), hi = gelu_erf_pair(f32x2{y[i][2], y[i][3]});
+                y[i][0] = lo.x; y[i][1] = lo.y; y[i][2] = hi.x; y[i][3] = hi.y;
             }
-            if constexpr (RES) { y[0] += res[t][i].x; y[1] += res[t][i].y; y[2] += res[t][i].z; y[3] += res[t][i].w; }
+            if constexpr (RES) { y[i][0] += res[t][i].x; y[i][1] += res[t][i].y; y[i][2] += res[t][i].z; y[i][3] += res[t][i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + 32 * t + 4 * i + r4;
             if (m >= a.M) continue;
             if constexpr (WIN) {
                 const int item = m / a.rows_per_item;
-                if (m - item * a.rows_per_item >= a.win[item].valid) y[0] = y[1] = y[2] = y[3] = 0.f;
+                if (m - item * a.rows_per_item >= a.win[item].valid) y[i][0] = y[i][1] = y[i][2] = y[i][3] = 0.f;
             }
             const size_t at = (size_t)m * (MODE == 3 ? a.ld_out : a.N) + fbase + 4 * c16;
-            if constexpr (OUT32) *reinterpret_cast<float4*>(a.out32 + at) = make_float4(y[0], y[1], y[2], y[3]);
-            if constexpr (OUT16) *reinterpret_cast<uint2*>(a.out16 + at * 2) = make_uint2(P::pack2(y[0], y[1]), P::pack2(y[2], y[3]));
+            if constexpr (OUT32) *reinterpret_cast<float4*>(a.out32 + at) = make_float4(y[i][0], y[i][1], y[i][2], y[i][3]);
+            if constexpr (OUT16) *reinterpret_cast<uint2*>(a.out16 + at * 2) = make_uint2(P::pack2(y[i][0], y[i][1]), P::pack2(y[i][2], y[i][3]));
         }
 #ifdef PPG_GEMM_TIMING
         if (t == 0) GSTAMP(10);

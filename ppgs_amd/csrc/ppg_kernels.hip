@@ -1780,7 +1780,7 @@ hipError_t launch_linear_p(int epi, int nb, int nt, const LinearArgs& a, int ypa
     case EPI_QKV:    return launch_linear_nt<P, 16, EPI_QKV>(nt, a, ypasses, s);
     case EPI_RELU:   return launch_linear_nt<P, 16, EPI_RELU>(nt, a, ypasses, s);
     case EPI_GELU:   return launch_linear_nt<P, 16, EPI_GELU>(nt, a, ypasses, s);
-    case EPI_GENERAL: return nb == 3 ? launch_linear_t<P, 1, 3, EPI_GENERAL>(a, ypasses, s) : launch_linear_nt<P, 16, EPI_GENERAL>(nt, a, ypasses, s);
+    case EPI_GENERAL: return nb == 3 ? launch_linear_nt<P, 3, EPI_GENERAL>(nt, a, ypasses, s) : launch_linear_nt<P, 16, EPI_GENERAL>(nt, a, ypasses, s);
     case EPI_OUTCONV:return launch_linear_nt<P, 3, EPI_OUTCONV>(nt, a, ypasses, s);
     case EPI_RESLN:
         // one 16-token block per wave: the LayerNorm epilogue holds a whole feature row per token in registers
