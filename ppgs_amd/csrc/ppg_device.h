@@ -623,6 +623,21 @@ struct Gemm32Args {
     int vt_ld, ld_out, v_pass0;
 };
 
+// ppg_posconv.hip: the wav2vec2 body's grouped positional convolution + GELU + residual (16 groups of 48, 128 taps)
+struct PosConvArgs {
+    const char* x16;          // [M][H] 16-bit operand rows (rows past an item's valid frames are zeros)
+    int ldx_bytes;
+    const char* w_img;        // A fragments [group 16][wave 4][tap 32][ks 3][rb 2] of 1 KiB: rows = features 32 rb + phi(l & 31)
+                              // of the group (>= 48: zeros), K = channels 16 ks + 8 (l >> 5) .. + 7 of tap 32 wave + tap
+    const float* bias;        // [H]
+    const float* residual;    // fp32 [M][H]
+    float* out32;             // fp32 [M][H]
+    int M, H;
+    int rows_per_item;        // item b owns rows b * rows_per_item ..; its first `frames` rows are the sequence
+    int frames;
+    int tiles_per_item;       // ceil(rows_per_item / 128)
+};
+
 // ppg_ffn32x2.hip: the FFN block in the fp16x2 mode on the feature-split machinery (96-token workgroups)
 struct Ffn32X2Args {
     const char* xb;           // [M][H] as [32 hi | 32 lo] fp16 blocks (PrecX2 rows, 4 bytes per element): the operand copy of X

@@ -1998,11 +1998,14 @@ struct PpgW2v2Body {
     char* proj_w = nullptr; float* proj_b = nullptr;
     char* proj_img = nullptr;      // the feature projection as gemm32 fragment images (16-bit modes)
     char* pos_w = nullptr; float* pos_b = nullptr;
+    char* pos_img = nullptr;       // the positional convolution's fragment image (ppg_posconv.hip, 16-bit modes)
+    bool posconv = true;           // PPGS_AMD_W2V2_POSCONV=0: the convolution as a k-tap GEMM on linear_kernel<EPI_GENERAL>
     float* en_g = nullptr; float* en_b = nullptr;
     struct Layer { char* wqkv; float* bqkv; char* wo; float* bo; float* g1; float* e1; char* w1; float* b1; char* w2; float* b2; float* g2; float* e2;
                    char* wo_img; char* w1_img; char* w2_img; char* wqkv_img; };   // fragment images for ppg_gemm32.hip (16-bit modes)
     bool gemm32 = true;            // PPGS_AMD_W2V2_GEMM32=0: linear_kernel<EPI_GENERAL> for every projection
     bool qkv32 = true;             // PPGS_AMD_W2V2_QKV32=0: Q/K/V on linear_kernel<EPI_QKV>
+    int attn_q = 64;               // PPGS_AMD_W2V2_ATTN_Q: queries per attention workgroup (64 or 128)
     std::vector<Layer> layer;
     // per pipeline (a batch of >= 8 items runs as two half-batches on two HIP streams, as the PPG network's engine does)
     struct Slot { char* staging = nullptr; size_t staging_bytes = 0; hipEvent_t uploaded = nullptr; };   // pinned tables of the call in flight
@@ -2049,6 +2052,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     m->eps = w->layer_norm_eps;
     if (const char* v = getenv("PPGS_AMD_W2V2_GEMM32")) m->gemm32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_W2V2_QKV32")) m->qkv32 = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_W2V2_ATTN_Q")) m->attn_q = atoi(v) == 128 ? 128 : 64;
     if (E->sz != 2 || H % 256 || F % 256 || H % 128 || F % 128) m->gemm32 = false;
     const int CG = H / w->conv_groups;                       // 48 channels per group
     m->gpt = (CG * E->sz + 63) / 64;                         // K-groups of 64 bytes per tap: 2 (16-bit, padded) or 3 (fp32)
@@ -2085,6 +2089,20 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
         if (rc) return rc;
     }
     if ((rc = upload_f32(E, w->pos_conv_bias, H, 0, &m->pos_b))) return rc;
+    if (const char* v = getenv("PPGS_AMD_W2V2_POSCONV")) m->posconv = atoi(v) != 0;
+    if (E->sz != 2 || w->conv_groups != 16 || CG != 48 || m->taps != 128) m->posconv = false;
+    if (m->posconv) {
+        const float* pw = w->pos_conv_weight;
+        const int frags = 16 * 4 * 32 * 6;
+        rc = upload_matrix(E, frags * 64, 8, frags * 64, 8,
+                           [&](int r, int j) {
+                               const int f = r >> 6, ln = r & 63;
+                               const int rb = f & 1, ks = (f % 6) >> 1, tl = (f / 6) & 31, wv = (f / 192) & 3, g = f / 768;
+                               const int n = 32 * rb + phi(ln & 31), ch = 16 * ks + 8 * (ln >> 5) + j, tap = 32 * wv + tl;
+                               return n < CG ? pw[((size_t)(g * CG + n) * CG + ch) * 128 + tap] : 0.f;
+                           }, &m->pos_img);
+        if (rc) return rc;
+    }
     if ((rc = upload_f32(E, w->enc_norm_weight, H, 0, &m->en_g))) return rc;
     if ((rc = upload_f32(E, w->enc_norm_bias, H, 0, &m->en_b))) return rc;
     m->layer.resize(L);
@@ -2251,7 +2269,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         w.item = b; w.frames = frames; w.valid = (int)valid_frames[b]; w.keep_lo = 0; w.keep_hi = frames;
         w.tok_off = b * R; w.vt_off = b * R;
         for (int k = 0; k < R / 16; ++k) hb[b * (R / 16) + k] = b;
-        for (int q0 = 0; q0 < frames; q0 += 64) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, 0, 0};
+        for (int q0 = 0; q0 < frames; q0 += m->attn_q) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, m->attn_q == 64, 0};
     }
     // padding rows, slack rows / columns of the OPERAND buffers: finite (masked keys are still multiplied).  The fp32
     // residual buffers X and P (half of the bytes) are written in full by the projection / every GEMM epilogue.
@@ -2311,6 +2329,13 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, a, H / 256, s), "w2v2 projection");
     }
     {   // positional convolution (+GELU) + residual -> P, then the encoder's LayerNorm
+        if (m->posconv) {
+            PosConvArgs pc{};
+            pc.x16 = Xb; pc.ldx_bytes = H * 2; pc.w_img = m->pos_img; pc.bias = m->pos_b; pc.residual = X; pc.out32 = P;
+            pc.M = M; pc.H = H; pc.rows_per_item = R; pc.frames = frames; pc.tiles_per_item = (R + 127) / 128;
+            LAUNCH_OK(ppg::launch_posconv(prec, pc, batch, s), "w2v2 positional convolution");
+            LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
+        } else {
         LinearArgs a = general(act_x, H, m->pos_w, m->pos_b, H);
         a.taps = m->taps; a.groups_per_tap = m->gpt; a.real_groups = a.total_groups = m->taps * m->gpt;
         a.act_y_stride = (H / m->groups) * sz; a.act_fn = 2; a.residual = X; a.out32 = P;
@@ -2320,6 +2345,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         if (const char* v = getenv("PPGS_AMD_W2V2_POS_NT")) pos_nt = std::max(1, std::min(atoi(v), sz == 2 ? 3 : 2));
         LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 3, pos_nt, a, m->groups, s), "w2v2 positional convolution");
         LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
+        }
     }
     for (int l = 0; l < m->layers; ++l) {
         const PpgW2v2Body::Layer& d = m->layer[l];

@@ -25,6 +25,8 @@ hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s);
 hipError_t launch_head32(int precision, const Head32Args& a, hipStream_t s);
 // the wide projections of the wav2vec2 body on the feature-split machinery (ppg_gemm32.hip): 16-bit precisions
 hipError_t launch_gemm32(int precision, const Gemm32Args& a, hipStream_t s);
+// grouped positional convolution + GELU + residual of the wav2vec2 body (ppg_posconv.hip): 16-bit precisions
+hipError_t launch_posconv(int precision, const PosConvArgs& a, int batch, hipStream_t s);
 hipError_t launch_ffn32x2(const Ffn32X2Args& a, hipStream_t s);
 int ffn32x2_tokens();
 // output convolution + mask + softmax with the weights resident in LDS (ppg_outconv.hip): 16-bit precisions, hidden 256, whole batches

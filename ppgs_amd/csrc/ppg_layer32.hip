@@ -447,10 +447,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             cstamp(0);
             const f32x16 bias = bias_of(braw);
             vm_wait_all(w1f);
+#ifdef PPG_L32_HOTW
+            // (experiment: every chunk reads chunk 0's weights -- wrong results, the weights always hot in L2)
+            const char* w2c = a.w2_img + (((size_t)0 * 4 + wave) * RB * 8) * 1024;
+            const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)0 * 4 + wave) * KS) * 1024
+#else
             const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;      // this chunk's W2 fragments [rb][ks8]
             // what goes into the W1 register set during phase B: the next chunk's fragments; after the last chunk the
             // first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
             const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
+#endif
                                 : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024);
             const int cn = c + 1 < NCH ? c + 1 : c;
             f32x16 hacc[TB];
