@@ -604,7 +604,8 @@ struct Head32Args {
 
 // ppg_gemm32.hip: Y = act_fn(X W^T + bias) [+ residual], 160 rows x 256 features per workgroup
 struct Gemm32Args {
-    const char* x;            // [M][K] 16-bit, row-major
+    const char* x;            // [M][K] 16-bit, row-major (row m at x + m * lda_bytes; lda_bytes 0 = K * 2.  Rows may overlap:
+                              // a strided k-tap convolution over [rows][C] is the GEMM with K = k * C, lda = stride * C)
     const char* w_img;        // A fragments [N / 256][wave][K / 128][rb][8 K-steps] of 1 KiB (rows in accumulator order phi)
     const float* bias;        // [N]
     const float* residual;    // fp32 [M][N] or null
@@ -621,6 +622,7 @@ struct Gemm32Args {
     // items start at multiples of 32 rows (rows_per_item % 32 == 0)
     char* vt;
     int vt_ld, ld_out, v_pass0;
+    int lda_bytes;
 };
 
 // ppg_posconv.hip: the wav2vec2 body's grouped positional convolution + GELU + residual (16 groups of 48, 128 taps)

@@ -1878,6 +1878,11 @@ struct PpgW2v2 {
     float* gamma = nullptr;
     float* beta = nullptr;
     char* w[kW2vLayers] = {};      // layers 1..6: [512 rows in paired order][taps * 512], GEMM operand type
+    // PPGS_AMD_W2V2_CONV32=1 (experiment): layers 1..6 as plain GEMMs on ppg_gemm32.hip (fragment images of the same
+    // weights).  Measured at 16 x 160 080 samples: 1.34 ms against 1.29 ms on linear_kernel<EPI_GELU> -- off.
+    char* w_img[kW2vLayers] = {};
+    float* zero_bias = nullptr;    // (the layers have no bias)
+    bool conv32 = false;
 };
 
 int ppg_w2v2_create(const PpgW2v2Weights* wts, int precision, int device, PpgW2v2** out) {
@@ -1913,6 +1918,30 @@ int ppg_w2v2_create(const PpgW2v2Weights* wts, int precision, int device, PpgW2v
                            &m->w[l]);
         if (rc) return rc;
     }
+    if (const char* v = getenv("PPGS_AMD_W2V2_CONV32")) m->conv32 = atoi(v) != 0;
+    if (E->sz != 2) m->conv32 = false;
+    if (m->conv32) {
+        // layers 1..6 as plain GEMMs on the feature-split kernel: output row m reads the k input rows 2 m .. as ONE
+        // contiguous run of K = k * 512 elements (rows of the input overlap: lda = 2 rows).  Images as the body's:
+        // [N / 256][wave][K / 128][rb][8 K-steps], rows in accumulator order phi, K index = tap * 512 + channel.
+        auto phi = [](int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); };
+        const int C = kW2vChannels;
+        for (int l = 1; l < kW2vLayers; ++l) {
+            const float* w = wts->conv_weight[l];
+            const int k = kW2vKernel[l], K = k * C, chunks = K / 128, frags = (C / 256) * 4 * chunks * 16;
+            rc = upload_matrix(E, frags * 64, 8, frags * 64, 8,
+                               [&](int r, int j) {
+                                   const int f = r >> 6, ln = r & 63;
+                                   const int ks = f & 7, rb = (f >> 3) & 1, c = (f >> 4) % chunks, wv = ((f >> 4) / chunks) & 3, p = (f >> 4) / chunks / 4;
+                                   const int n = 256 * p + 64 * wv + 32 * rb + phi(ln & 31), kk = 128 * c + 16 * ks + 8 * (ln >> 5) + j;
+                                   const int tap = kk / C, ch = kk - tap * C;
+                                   return w[((size_t)n * C + ch) * k + tap];
+                               }, &m->w_img[l]);
+            if (rc) return rc;
+        }
+        std::vector<float> zeros(C, 0.f);
+        if ((rc = upload_f32(E, zeros.data(), C, 0, &m->zero_bias))) return rc;
+    }
     *out = m.release();
     return PPG_OK;
 }
@@ -1931,8 +1960,9 @@ int ppg_w2v2_workspace_bytes(const PpgW2v2* model, int batch, int64_t samples, s
     const size_t row = (size_t)kW2vChannels * model->eng.sz;
     size_t total = align_up((size_t)batch * 65 * sizeof(double), 256);
     total += align_up((size_t)batch * kW2vChannels * sizeof(float2), 256);
-    total += align_up((size_t)batch * sh.R[0] * row, 256);
-    total += align_up((size_t)batch * sh.R[1] * row, 256);
+    // (+ 1 row: the last output row of a 3-tap layer reads one row past its input -- a padding row nobody consumes)
+    total += align_up(((size_t)batch * sh.R[0] + 1) * row, 256);
+    total += align_up(((size_t)batch * sh.R[1] + 1) * row, 256);
     *bytes = total;
     return PPG_OK;
 }
@@ -1957,13 +1987,21 @@ int ppg_w2v2_features(PpgW2v2* model, const float* audio, int batch, int64_t sam
     off += align_up((size_t)batch * kW2vChannels * sizeof(float2), 256);
     char* bufs[2];
     bufs[0] = base + off;
-    off += align_up((size_t)batch * sh.R[0] * row, 256);
+    off += align_up(((size_t)batch * sh.R[0] + 1) * row, 256);
     bufs[1] = base + off;
     const int prec = E->cfg.precision;
     hipError_t he = ppg::launch_w2v2_layer0(prec, audio, batch, samples, sh.T[0], (int)sh.R[0], model->w0, model->gamma, model->beta,
                                             moments, scale_shift, bufs[0], s);
     if (he != hipSuccess) return fail(PPG_EDEVICE, "w2v2 layer 0: %s", hipGetErrorString(he));
     for (int l = 1; l < kW2vLayers; ++l) {
+        if (model->conv32 && kW2vStride[l] == 2 && kW2vKernel[l] * kW2vChannels >= 384) {
+            Gemm32Args g{};
+            g.x = bufs[(l - 1) & 1]; g.lda_bytes = (int)(kW2vStride[l] * row); g.w_img = model->w_img[l]; g.bias = model->zero_bias;
+            g.out16 = bufs[l & 1]; g.M = (int)(batch * sh.R[l]); g.N = kW2vChannels; g.K = kW2vKernel[l] * kW2vChannels; g.act_fn = 2;
+            he = ppg::launch_gemm32(prec, g, s);
+            if (he != hipSuccess) return fail(PPG_EDEVICE, "w2v2 conv layer %d: %s", l, hipGetErrorString(he));
+            continue;
+        }
         LinearArgs a{};
         a.v_start = INT_MAX;
         a.act = bufs[(l - 1) & 1]; a.lda_bytes = (int)row; a.taps = kW2vKernel[l];

@@ -72,8 +72,9 @@ __device__ __forceinline__ void gemm32_body(const Gemm32Args& a, char* smem) {
     const int srow = SROWS * wave + (lane >> 4), scol = (lane & 15) * 16;
     u32x4 stg[NST];
     const char* xrow[NST];
+    const size_t lda = a.lda_bytes ? (size_t)a.lda_bytes : (size_t)a.K * 2;
 #pragma unroll
-    for (int i = 0; i < NST; ++i) xrow[i] = a.x + (size_t)min(m0 + srow + 4 * i, a.M - 1) * a.K * 2 + scol;   // rows past M re-read the last one (never stored)
+    for (int i = 0; i < NST; ++i) xrow[i] = a.x + (size_t)min(m0 + srow + 4 * i, a.M - 1) * lda + scol;   // rows past M re-read the last one (never stored)
     auto fetch = [&](int c) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[i]) : "v"(xrow[i] + (size_t)c * KC * 2) : "memory");

@@ -55,10 +55,13 @@ def feature_encoder_for(device, model):
     """Cached HIP feature encoder holding `model`'s convolution weights."""
     from .. import core, engine
     key = (str(device), id(model), core.PRECISION)
-    if key not in _encoders:
-        _encoders[key] = engine.W2v2FeatureEncoder(
-            model.feature_extractor.state_dict(), device.index, core.PRECISION)
-    return _encoders[key]
+    entry = _encoders.get(key)
+    # (the entry keeps the model alive: the id of a freed model can be handed to the next one, and an engine found
+    # under it would hold the OLD model's weights)
+    if entry is None or entry[0] is not model:
+        entry = _encoders[key] = (model, engine.W2v2FeatureEncoder(
+            model.feature_extractor.state_dict(), device.index, core.PRECISION))
+    return entry[1]
 
 
 _bodies = {}
@@ -68,9 +71,17 @@ def body_for(device, model):
     """Cached HIP transformer body holding `model`'s projection / encoder weights."""
     from .. import core, engine
     key = (str(device), id(model), core.PRECISION)
-    if key not in _bodies:
-        _bodies[key] = engine.W2v2Body(model, device.index, core.PRECISION)
-    return _bodies[key]
+    entry = _bodies.get(key)
+    if entry is None or entry[0] is not model:
+        entry = _bodies[key] = (model, engine.W2v2Body(model, device.index, core.PRECISION))
+    return entry[1]
+
+
+def clear():
+    """Drop the cached models and the HIP engines built from them."""
+    _models.clear()
+    _encoders.clear()
+    _bodies.clear()
 
 
 def last_hidden_state(model, padded, mask):

@@ -905,7 +905,7 @@ def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
     monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
     import transformers
     from ppgs_amd.preprocess import w2v2fb
-    w2v2fb._models.clear()
+    w2v2fb.clear()
     gen = torch.Generator().manual_seed(2)
     audio = 0.1 * torch.randn(2, 1, 16000, generator=gen)
     lengths = torch.tensor([16000, 12000])
@@ -928,7 +928,7 @@ def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
     ppg = engine.encode(feats, frames).cpu().numpy()
     oracle = O.from_features(state, feats.cpu(), frames).numpy()
     assert np.abs(ppg - oracle).max() < FP32_TOL
-    w2v2fb._models.clear()
+    w2v2fb.clear()
 
 
 def test_graphed_encode_helper():
@@ -1235,7 +1235,7 @@ def test_c3_full_size_body_and_ppg_network(monkeypatch):
     latents against the CPU oracle on spot items, 1e-4."""
     monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
     from ppgs_amd.preprocess import w2v2fb
-    w2v2fb._models.clear()
+    w2v2fb.clear()
     old = ppgs_amd.core.PRECISION
     ppgs_amd.core.PRECISION = 'fp32'
     try:
@@ -1278,7 +1278,7 @@ def test_c3_full_size_body_and_ppg_network(monkeypatch):
                 assert np.abs(fast[item, :, :frames[item]].cpu().numpy() - oracle[row, :, :frames[item]]).max() < TOL[precision], (precision, item)
     finally:
         ppgs_amd.core.PRECISION = old
-        w2v2fb._models.clear()
+        w2v2fb.clear()
 
 
 def test_c4_thousand_utterances_slice():

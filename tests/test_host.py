@@ -264,3 +264,35 @@ def test_bind_cpus_against_a_faked_two_socket_eight_gpu_tree(tmp_path):
     assert distributed.cpu_slice(1, 2, range(16), [-1, -1], {}) == list(range(8, 16))
     assert distributed.cpu_slice(0, 8, range(8), [0] * 8, {0: set(range(8))}) == []
     assert distributed.cpu_slice(3, 4, range(64), [0, 0, 1, 1], {0: set(range(32)), 1: set(range(32, 64))}) == list(range(48, 64))
+
+
+def test_w2v2fb_engine_cache_is_bound_to_the_model_object(monkeypatch):
+    """The HIP engines of the w2v2fb representation are cached per (device, model, precision).  The key holds id(model):
+    the entry must keep the model alive and be checked against the object -- a freed model's id can be handed to the
+    next model, and an engine found under it would hold the old weights (seen as an intermittent GPU test failure)."""
+    import types
+    import torch
+    from ppgs_amd import engine
+    from ppgs_amd.preprocess import w2v2fb
+    built = []
+
+    class Fake:
+        def __init__(self, *args):
+            built.append(args)
+    monkeypatch.setattr(engine, 'W2v2FeatureEncoder', Fake)
+    monkeypatch.setattr(engine, 'W2v2Body', Fake)
+    w2v2fb.clear()
+    device = torch.device('cuda', 0)
+    make = lambda: types.SimpleNamespace(feature_extractor=types.SimpleNamespace(state_dict=lambda: {}))
+    a, b = make(), make()
+    ea, ba = w2v2fb.feature_encoder_for(device, a), w2v2fb.body_for(device, a)
+    assert w2v2fb.feature_encoder_for(device, a) is ea and w2v2fb.body_for(device, a) is ba and len(built) == 2
+    # an entry under b's key that belongs to another model (what id reuse produces) is not handed out
+    from ppgs_amd import core
+    w2v2fb._encoders[(str(device), id(b), core.PRECISION)] = w2v2fb._encoders[(str(device), id(a), core.PRECISION)]
+    w2v2fb._bodies[(str(device), id(b), core.PRECISION)] = w2v2fb._bodies[(str(device), id(a), core.PRECISION)]
+    assert w2v2fb.feature_encoder_for(device, b) is not ea and w2v2fb.body_for(device, b) is not ba and len(built) == 4
+    # and the cache holds the models
+    assert any(entry[0] is a for entry in w2v2fb._encoders.values())
+    w2v2fb.clear()
+    assert not w2v2fb._encoders and not w2v2fb._bodies and not w2v2fb._models
