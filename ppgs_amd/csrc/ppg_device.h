@@ -300,28 +300,16 @@ __device__ __forceinline__ float wave_max_g(float v) {
     return max3(__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[1]));
 }
 
-// GELU(x) = x Phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 on erf, far inside the fp32
-// parity bar and the 16-bit operand roundings): 1 v_rcp + 1 v_exp + ~10 FMAs instead of libm erff's ~30 instructions
-// with branches -- at the wav2vec2 widths the activation costs as many issue cycles as the GEMM in front of it.
-// The negative side is computed as 0.5 x p e^{-z^2} directly (no 1 - (1 - ..) cancellation).
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float half_tail = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 0.5 (1 - erf |z|)
-    return x >= 0.f ? x - x * half_tail : x * half_tail;
-}
-
-// The same function for two values at once, built for the packed fp32 instructions (v_pk_mul / v_pk_fma: two values
-// per issue slot) and ONE transcendental per value: 0.5 erfc(z) = 0.5 exp2(-z G(z)), G a degree-7 polynomial fitted
-// to -log2(erfc z) / z on [0, 4.3] (weighted by the sensitivity z erfc z; z is clamped there: erfc(4.3) = 1e-9), and
-// gelu(x) = max(x, 0) - (1 / sqrt 2) z erfc(z) / ... i.e. max(x, 0) - 0.7071 z exp2(-z G) with z = |x| / sqrt 2
-// (x >= 0: x - x * 0.5 erfc; x < 0: x * 0.5 erfc).  Max abs error against the exact function 5.0e-7 over [-8, 8] in
-// fp32 evaluation (the 7.1.26 form above: 5.2e-7); 15 instructions per PAIR against 28.  ppg_gemm32.hip's FFN epilogue.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Exact (erf-form) GELU, torch.nn.functional.gelu's default: gelu(x) = x Phi(x).  Built for the packed fp32
+// instructions (v_pk_mul / v_pk_fma: two values per issue slot) and ONE transcendental per value:
+//     0.5 erfc(z) = 0.5 exp2(-z G(z)),   z = |x| / sqrt 2,
+// G a degree-7 polynomial fitted here to -log2(erfc z) / z on [0, 4.3] (least squares re-weighted towards minimax,
+// weight = the sensitivity z erfc z; z is clamped to 4.3: erfc(4.3) = 1e-9), and
+//     gelu(x) = max(x, 0) - (1 / sqrt 2) z exp2(-z G(z))        (x >= 0: x - x 0.5 erfc z;  x < 0: x 0.5 erfc z)
+// -- no 1 - (1 - ..) cancellation on the negative side, no division.  Max abs error against the exact function over
+// [-8, 8], evaluated in fp32: 5.0e-7 (the Abramowitz & Stegun 7.1.26 form used until round 4: 5.2e-7, with a
+// reciprocal and an exponential per value: 28 instructions per pair against 15).  At the wav2vec2 widths the
+// activation costs as many issue cycles as the GEMM in front of it.
 __device__ __forceinline__ f32x2 gelu_erf_pair(f32x2 x) {
     const f32x2 z = {fminf(fabsf(x.x) * 0.70710678118654752f, 4.3f), fminf(fabsf(x.y) * 0.70710678118654752f, 4.3f)};
     f32x2 g = z * 4.5357837683e-05f + -4.4550141416e-04f;
@@ -335,6 +323,17 @@ __device__ __forceinline__ f32x2 gelu_erf_pair(f32x2 x) {
     const f32x2 e = {__builtin_amdgcn_exp2f(-arg.x), __builtin_amdgcn_exp2f(-arg.y)};
     const f32x2 pos = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
     return pos - (z * e) * 0.70710678118654752f;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fminf(fabsf(x) * 0.70710678118654752f, 4.3f);
+    float g = fmaf(z, 4.5357837683e-05f, -4.4550141416e-04f);
+    g = fmaf(g, z, 1.4894216193e-03f);
+    g = fmaf(g, z, 7.7466185625e-04f);
+    g = fmaf(g, z, -2.8253708586e-02f);
+    g = fmaf(g, z, 1.4848162721e-01f);
+    g = fmaf(g, z, 9.1841639080e-01f);
+    g = fmaf(g, z, 1.6279085932e+00f);
+    return fmaf(z * __builtin_amdgcn_exp2f(-(z * g)), -0.70710678118654752f, fmaxf(x, 0.f));
 }
 
 // Epilogue kinds of linear_kernel

@@ -620,7 +620,6 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
     } else if constexpr (EPI == EPI_GELU) {
         // exact GELU (erf form, torch.nn.functional.gelu default); W rows in paired order: 16-byte stores
         PairStore<P> pair[NT];
-        auto gelu = [](float x) { return gelu_erf(x); };
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = n0 + pair_feature(nb, g);
@@ -628,14 +627,13 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             for (int t = 0; t < NT; ++t) {
                 const int m = tok0 + 16 * t + idx;
                 if (m >= a.M) continue;
-                pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1,
-                            gelu(acc[nb][t][0]), gelu(acc[nb][t][1]), gelu(acc[nb][t][2]), gelu(acc[nb][t][3]));
+                const f32x2 lo = gelu_erf_pair(f32x2{acc[nb][t][0], acc[nb][t][1]}), hi = gelu_erf_pair(f32x2{acc[nb][t][2], acc[nb][t][3]});
+                pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1, lo.x, lo.y, hi.x, hi.y);
             }
         }
     } else if constexpr (EPI == EPI_GENERAL) {
         // y = act_fn(acc + bias) [zeroed past the window's valid rows] [+ residual] -> fp32 rows and / or 16-bit rows.
         // NB == 16: W rows in paired order (16-byte stores of the 16-bit copy); other NB: plain order, fp32 output only.
-        auto gelu = [](float x) { return gelu_erf(x); };
         PairStore<P> pair[NT];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -647,8 +645,8 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 if (m >= a.M) continue;
                 float y[4] = {acc[nb][t][0] + bv.x, acc[nb][t][1] + bv.y, acc[nb][t][2] + bv.z, acc[nb][t][3] + bv.w};
                 if (a.act_fn == 2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = gelu(y[r]);
+                    const f32x2 lo = gelu_erf_pair(f32x2{y[0], y[1]}), hi = gelu_erf_pair(f32x2{y[2], y[3]});
+                    y[0] = lo.x; y[1] = lo.y; y[2] = hi.x; y[3] = hi.y;
                 } else if (a.act_fn == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void w2v2_conv0_kernel(const float* audio, lon
                 y0 = fmaf(w[0][j], v, y0);
                 y1 = fmaf(w[1][j], v, y1);
             }
-            y0 = gelu_exact(fmaf(ss0.x, y0, ss0.y));
-            y1 = gelu_exact(fmaf(ss1.x, y1, ss1.y));
+            const f32x2 gy = gelu_erf_pair(f32x2{fmaf(ss0.x, y0, ss0.y), fmaf(ss1.x, y1, ss1.y)});
+            y0 = gy.x; y1 = gy.y;
         }
         if (t0 + t < rows_per_item) {
             if constexpr (P::kIsBF16) *reinterpret_cast<uint32_t*>(dst + (size_t)t * W2V_C) = P::pack2(y0, y1);
