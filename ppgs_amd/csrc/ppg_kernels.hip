@@ -558,12 +558,18 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             }
         }
     } else if constexpr (EPI == EPI_QKV) {
+        // The pass's bias values go through LDS (the weight tiles are done with: the loop ended on a barrier).  Read
+        // from global memory inside the store loop, every load waited -- vmcnt(0), the compiler's count across the
+        // `m < M` control flow -- for the previous block's STORE to be acknowledged (tools/wait_scan.py).
+        float* lbias = reinterpret_cast<float*>(smem);
+        if (tid < NB * 4) reinterpret_cast<float4*>(lbias)[tid] = reinterpret_cast<const float4*>(a.bias + n0)[tid];
+        __syncthreads();
         if (!swap) {
             PairStore<P> pair[NT];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int n = n0 + pair_feature(nb, g);
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);     // once for all token blocks
+                const float4 bv = *reinterpret_cast<const float4*>(lbias + pair_feature(nb, g));     // once for all token blocks
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int m = tok0 + 16 * t + idx;
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int row = n0 + nb * 16 + idx;                       // tile row
-                    const float bv = a.bias[n0 + pair_row(nb * 16 + idx)];
+                    const float bv = lbias[pair_row(nb * 16 + idx)];
                     char* dst = a.vt + (size_t)(row - a.v_start) * a.vt_ld * P::kBytes + P::row_byte(vcol[t] + ((P::kIsBF16 || P::kSplit) ? 8 : 4) * g);
                     if constexpr (P::kSplit) {
                         if (paired) {          // both planes of the 8 columns of the (even, odd) block pair
@@ -635,10 +641,13 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
         // y = act_fn(acc + bias) [zeroed past the window's valid rows] [+ residual] -> fp32 rows and / or 16-bit rows.
         // NB == 16: W rows in paired order (16-byte stores of the 16-bit copy); other NB: plain order, fp32 output only.
         PairStore<P> pair[NT];
+        float* lbias = reinterpret_cast<float*>(smem);       // (as EPI_QKV: the bias through LDS)
+        if (tid < NB * 4) reinterpret_cast<float4*>(lbias)[tid] = reinterpret_cast<const float4*>(a.bias + n0)[tid];
+        __syncthreads();
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = n0 + (NB == 16 ? pair_feature(nb, g) : nb * 16 + 4 * g);
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+            const float4 bv = *reinterpret_cast<const float4*>(lbias + (n - n0));
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int m = tok0 + 16 * t + idx;
@@ -666,6 +675,9 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             }
         }
     } else if constexpr (EPI == EPI_RELU) {
+        float* lbias = reinterpret_cast<float*>(smem);       // (as EPI_QKV: no global load between the stores)
+        if (tid < NB * 4) reinterpret_cast<float4*>(lbias)[tid] = reinterpret_cast<const float4*>(a.bias + n0)[tid];
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int m = tok0 + 16 * t + idx;
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int n = n0 + nb * 16 + 4 * g;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                const float4 bv = *reinterpret_cast<const float4*>(lbias + nb * 16 + 4 * g);
                 store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes,
                           fmaxf(acc[nb][t][0] + bv.x, 0.f), fmaxf(acc[nb][t][1] + bv.y, 0.f),
                           fmaxf(acc[nb][t][2] + bv.z, 0.f), fmaxf(acc[nb][t][3] + bv.w, 0.f));
