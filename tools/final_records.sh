@@ -27,6 +27,8 @@ timeout 300 python bench.py --precision fp16x2 --no-alt --no-cpu --steps 20 --wa
 find gpurun_out/prof_${tag}_one/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_one_pipeline_kernel_stats.csv
 timeout 900 bash tests/prof_configs.sh $tag > $out/prof_configs.log 2>&1
 for c in c3 c5 c5stream; do cp gpurun_out/prof_${tag}_$c/kernel_stats.csv $out/${tag}_kernel_stats_$c.csv; done
+timeout 600 bash tests/prof_body.sh $tag > $out/prof_body.log 2>&1
+for n in one two; do cp gpurun_out/prof_${tag}_body/by_grid_${n}_pipelines.txt $out/${tag}_body_by_grid_${n}_pipelines.txt; done
 timeout 600 python tools/bench_c3.py > $out/c3.log 2>&1; grep "^{" $out/c3.log | tail -1 > $out/${tag}_bench_c3.json
 PPGS_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload c4 > $out/c4.log 2>&1; grep "^{" $out/c4.log | tail -1 > $out/${tag}_bench_c4.json
 timeout 300 python tools/bench_streaming.py > $out/c5.log 2>&1; grep "^{" $out/c5.log | tail -1 > $out/${tag}_bench_c5.json
