@@ -7,11 +7,9 @@ out=gpurun_out/final_$tag
 mkdir -p $out
 timeout 1800 python -m pytest tests -m gpu -q > $out/gputests.log 2>&1; tail -n 3 $out/gputests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -n 5 $out/smoke.log
-# the driver's command first (a fresh process, 20 steps), then the default line
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.log 2>&1; grep "^{" $out/bench_driver.log | tail -1 > $out/${tag}_bench.json
-timeout 400 python bench.py > $out/bench_default.log 2>&1; grep "^{" $out/bench_default.log | tail -1 > $out/${tag}_bench_1000steps.json
-PPGS_AMD_STREAMS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-alt > $out/bench_one.log 2>&1; grep "^{" $out/bench_one.log | tail -1 > $out/${tag}_one_pipeline_bench.json
-timeout 300 python bench.py --precision fp32 --no-alt --no-cpu --steps 20 --warmup 5 > $out/bench_fp32.log 2>&1; grep "^{" $out/bench_fp32.log | tail -1 > $out/${tag}_bench_fp32.json
+# the counter passes first: bench.py quotes roofline.traffic / mfma_busy_frac from the PMC summary under profiles/ whose
+# header names the library it has loaded -- the summaries of THIS build are installed there (in this box's copy of the
+# tree; copy them into the real profiles/ afterwards) before the bench lines are taken
 timeout 900 bash tests/prof.sh $tag > $out/prof.log 2>&1
 python tests/pmc_summary.py gpurun_out/prof_$tag/pmc*/bench_counter_collection.csv > $out/${tag}_pmc_summary.txt 2>$out/pmc_summary.err
 find gpurun_out/prof_$tag/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats.csv
@@ -21,6 +19,14 @@ find gpurun_out/prof_$tag/trace -name "*kernel_stats.csv" | head -1 | xargs -I{}
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_x2/pmc1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision fp16x2 --no-cpu --no-alt --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/$out/prof_x2_pmc.log 2>&1 )
 python tests/pmc_summary.py gpurun_out/prof_${tag}_x2/pmc1/bench_counter_collection.csv > $out/${tag}_pmc_summary_fp16x2.txt 2>>$out/pmc_summary.err
 find gpurun_out/prof_${tag}_x2/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats_fp16x2.csv
+round=$(echo $tag | sed 's/^\(r[0-9]*\).*/\1/')
+cp $out/${tag}_pmc_summary.txt profiles/${round}_pmc_summary.txt
+cp $out/${tag}_pmc_summary_fp16x2.txt profiles/${round}_pmc_summary_fp16x2.txt
+# the driver's command first (a fresh process, 20 steps), then the default line
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.log 2>&1; grep "^{" $out/bench_driver.log | tail -1 > $out/${tag}_bench.json
+timeout 400 python bench.py > $out/bench_default.log 2>&1; grep "^{" $out/bench_default.log | tail -1 > $out/${tag}_bench_1000steps.json
+PPGS_AMD_STREAMS=1 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-alt > $out/bench_one.log 2>&1; grep "^{" $out/bench_one.log | tail -1 > $out/${tag}_one_pipeline_bench.json
+timeout 300 python bench.py --precision fp32 --no-alt --no-cpu --steps 20 --warmup 5 > $out/bench_fp32.log 2>&1; grep "^{" $out/bench_fp32.log | tail -1 > $out/${tag}_bench_fp32.json
 timeout 300 python bench.py --precision fp16x2 --no-alt --no-cpu --steps 20 --warmup 5 > $out/bench_x2.log 2>&1; grep "^{" $out/bench_x2.log | tail -1 > $out/${tag}_bench_fp16x2.json
 # one pipeline under the profiler: the per-kernel whole-chip figures
 ( cd /tmp && export TMPDIR=/tmp && PPGS_AMD_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_one/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-alt --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/prof_one.log 2>&1 )
