@@ -1112,6 +1112,38 @@ def test_w2v2_body_shapes_vs_hf_modules():
             assert (out[item, :count] - ref[item, :count]).abs().max() < 1e-4, (shape, item)
 
 
+@pytest.mark.parametrize('precision', ['fp16', 'bf16'])
+def test_w2v2_body_16bit_kernels_at_odd_shapes(monkeypatch, precision):
+    """The 16-bit modes' own kernels of the body (ppg_gemm32.hip for every projection, ppg_posconv.hip) at the sizes
+    the fixture does not reach -- row counts that are not whole tiles (9 x 77 frames: 864 rows), one-frame items, 1499
+    frames, ragged masks, a two-pipeline batch: against the HF modules on the same GPU (the fixture test's tolerances)
+    and against the same mode on the token-split kernels (PPGS_AMD_W2V2_GEMM32=0, _POSCONV=0: same operand roundings,
+    another summation order; measured 6e-4 / 4.5e-3)."""
+    import transformers
+    transformers.utils.logging.set_verbosity_error()
+    torch.manual_seed(5)
+    model = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(num_hidden_layers=2)).eval().cuda()
+    gen = torch.Generator().manual_seed(3)
+    tol_ref, tol_old = {'fp16': (1e-2, 2e-3), 'bf16': (6e-2, 1.5e-2)}[precision]
+    cases = (((1, 1499, 512), [1499]), ((2, 33, 512), [33, 1]), ((5, 1, 512), [1] * 5), ((3, 257, 512), [257, 200, 129]),
+             ((9, 77, 512), [77, 1, 40, 77, 76, 33, 64, 65, 77]), ((1, 160, 512), [160]), ((16, 499, 512), [499] * 15 + [250]))
+    new_body = E.W2v2Body(model, 0, precision)
+    monkeypatch.setenv('PPGS_AMD_W2V2_GEMM32', '0')
+    monkeypatch.setenv('PPGS_AMD_W2V2_POSCONV', '0')
+    old_body = E.W2v2Body(model, 0, precision)
+    for shape, valid in cases:
+        x = torch.randn(*shape, generator=gen).cuda()
+        mask = torch.arange(shape[1], device='cuda')[None] < torch.tensor(valid, device='cuda')[:, None]
+        with torch.no_grad():
+            hidden, _ = model.feature_projection(x)
+            ref = model.encoder(hidden, attention_mask=mask).last_hidden_state
+        new, old = new_body(x, valid).clone(), old_body(x, valid).clone()
+        assert torch.isfinite(new).all()
+        for item, count in enumerate(valid):
+            assert (new[item, :count] - ref[item, :count]).abs().max() < tol_ref, (shape, item)
+            assert (new[item, :count] - old[item, :count]).abs().max() < tol_old, (shape, item)
+
+
 def test_w2v2_body_two_pipelines_equal_one(monkeypatch):
     """A batch of >= 8 items (>= 4096 rows) runs as two half-batches on two HIP streams of the body
     (PPGS_AMD_W2V2_STREAMS=1: one): the same bits, odd batch sizes and ragged masks included."""
