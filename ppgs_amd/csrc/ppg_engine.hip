@@ -2043,14 +2043,11 @@ struct PpgW2v2Body {
                    char* wo_img; char* w1_img; char* w2_img; char* wqkv_img; };   // fragment images for ppg_gemm32.hip (16-bit modes)
     bool gemm32 = true;            // PPGS_AMD_W2V2_GEMM32=0: linear_kernel<EPI_GENERAL> for every projection
     bool qkv32 = true;             // PPGS_AMD_W2V2_QKV32=0: Q/K/V on linear_kernel<EPI_QKV>
-    int attn_q = 64;               // PPGS_AMD_W2V2_ATTN_Q: queries per attention workgroup (64 or 128)
     std::vector<Layer> layer;
     // per pipeline (a batch of >= 8 items runs as two half-batches on two HIP streams, as the PPG network's engine does)
     struct Slot { char* staging = nullptr; size_t staging_bytes = 0; hipEvent_t uploaded = nullptr; };   // pinned tables of the call in flight
     Slot slot[2];
     int pipelines = 2;             // PPGS_AMD_W2V2_STREAMS
-    int ablate = 0;                // PPGS_AMD_W2V2_ABLATE (timing experiments, wrong results): 1 no GELU in FFN-1, 2 no LayerNorm launches,
-                                   // 4 no attention, 8 no Q/K/V, 16 no out-proj, 32 no FFN-1, 64 no FFN-2
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~PpgW2v2Body() {
@@ -2090,7 +2087,6 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     m->eps = w->layer_norm_eps;
     if (const char* v = getenv("PPGS_AMD_W2V2_GEMM32")) m->gemm32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_W2V2_QKV32")) m->qkv32 = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_W2V2_ATTN_Q")) m->attn_q = atoi(v) == 128 ? 128 : 64;
     if (E->sz != 2 || H % 256 || F % 256 || H % 128 || F % 128) m->gemm32 = false;
     const int CG = H / w->conv_groups;                       // 48 channels per group
     m->gpt = (CG * E->sz + 63) / 64;                         // K-groups of 64 bytes per tap: 2 (16-bit, padded) or 3 (fp32)
@@ -2201,7 +2197,6 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (const char* v = getenv("PPGS_AMD_W2V2_STREAMS")) m->pipelines = std::max(1, std::min(atoi(v), 2));
-    if (const char* v = getenv("PPGS_AMD_W2V2_ABLATE")) m->ablate = atoi(v);
     *out = m.release();
     return PPG_OK;
 }
@@ -2307,7 +2302,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         w.item = b; w.frames = frames; w.valid = (int)valid_frames[b]; w.keep_lo = 0; w.keep_hi = frames;
         w.tok_off = b * R; w.vt_off = b * R;
         for (int k = 0; k < R / 16; ++k) hb[b * (R / 16) + k] = b;
-        for (int q0 = 0; q0 < frames; q0 += m->attn_q) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, m->attn_q == 64, 0};
+        for (int q0 = 0; q0 < frames; q0 += 64) hi[ni++] = AttnItem{b, q0, w.tok_off, w.vt_off, frames, w.valid, 0, 0};
     }
     // padding rows, slack rows / columns of the OPERAND buffers: finite (masked keys are still multiplied).  The fp32
     // residual buffers X and P (half of the bytes) are written in full by the projection / every GEMM epilogue.
@@ -2347,9 +2342,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         a.W = W; a.bias = bias; a.N = N; a.out_ld32 = H;
         return a;
     };
-    const int abl = m->ablate;
     auto layer_norm = [&](const float* g, const float* b) {
-        if (abl & 2) return hipSuccess;
         return ppg::launch_w2v2_layernorm(prec, H, P, nullptr, g, b, M, M, M, m->eps, X, xb_out, s);
     };
     // feature projection: LayerNorm(512) -> Linear, rows past the valid frames zeroed (HF: hidden_states[~mask] = 0)
@@ -2390,8 +2383,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         {
             LinearArgs a = general(act_x, H, d.wqkv, d.bqkv, 3 * H);
             a.out_rows = qk; a.out_ld = 2 * H; a.vt = vt; a.vt_ld = vt_ld; a.v_start = 2 * H;
-            if (abl & 8) {
-            } else if (m->gemm32 && m->qkv32) {
+            if (m->gemm32 && m->qkv32) {
                 Gemm32Args g{};
                 g.x = Xb; g.w_img = d.wqkv_img; g.bias = d.bqkv; g.out16 = qk; g.M = M; g.N = 3 * H; g.K = H;
                 g.vt = vt; g.vt_ld = vt_ld; g.ld_out = 2 * H; g.v_pass0 = 2 * H / 256; g.rows_per_item = R;
@@ -2400,7 +2392,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
                 LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, nt, a, 3 * H / 256, s), "w2v2 qkv");
             }
         }
-        if (!(abl & 4)) {
+        {
             AttnArgs a{};
             a.qk = qk; a.qk_ld_bytes = 2 * H * sz; a.vt = vt; a.vt_ld_bytes = vt_ld * sz;
             a.ao = ao; a.H = H; a.causal = 0;
@@ -2410,14 +2402,14 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         if (m->gemm32) {
             Gemm32Args g{};
             g.x = ao; g.w_img = d.wo_img; g.bias = d.bo; g.residual = X; g.out32 = P; g.M = M; g.N = H; g.K = H;
-            if (!(abl & 16)) LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 out-proj");
+            LAUNCH_OK(ppg::launch_gemm32(prec, g, s), "w2v2 out-proj");
             LAUNCH_OK(layer_norm(d.g1, d.e1), "w2v2 LayerNorm 1");
             Gemm32Args f1{};
-            f1.x = Xb; f1.w_img = d.w1_img; f1.bias = d.b1; f1.out16 = hid; f1.M = M; f1.N = F; f1.K = H; f1.act_fn = (abl & 1) ? 0 : 2;
-            if (!(abl & 32)) LAUNCH_OK(ppg::launch_gemm32(prec, f1, s), "w2v2 ffn 1");
+            f1.x = Xb; f1.w_img = d.w1_img; f1.bias = d.b1; f1.out16 = hid; f1.M = M; f1.N = F; f1.K = H; f1.act_fn = 2;
+            LAUNCH_OK(ppg::launch_gemm32(prec, f1, s), "w2v2 ffn 1");
             Gemm32Args f2{};
             f2.x = hid; f2.w_img = d.w2_img; f2.bias = d.b2; f2.residual = X; f2.out32 = P; f2.M = M; f2.N = H; f2.K = F;
-            if (!(abl & 64)) LAUNCH_OK(ppg::launch_gemm32(prec, f2, s), "w2v2 ffn 2");
+            LAUNCH_OK(ppg::launch_gemm32(prec, f2, s), "w2v2 ffn 2");
             LAUNCH_OK(layer_norm(d.g2, d.e2), "w2v2 LayerNorm 2");
             continue;
         }

@@ -1761,17 +1761,6 @@ __global__ __launch_bounds__(256, 2) void attn_mixed_kernel(AttnArgs a) {
     else attn_body<P, 2, 128, 4>(a, item, head, smem);
 }
 
-// Head dimension 64 (wav2vec2 body) with the same two tile widths: item.narrow picks 64 queries, else 128
-template <class P>
-__global__ __launch_bounds__(256, 2) void attn_mixed64_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int item_index = blockIdx.x / a.heads;
-    const AttnItem item = a.items[item_index];
-    const int head = blockIdx.x - item_index * a.heads;
-    if (item.narrow) attn_body<P, 1, 64, 4>(a, item, head, smem);
-    else attn_body<P, 2, 64, 4>(a, item, head, smem);
-}
-
 template <class P, int NT, int NB, int EPI>
 hipError_t launch_linear_t(const LinearArgs& a, int ypasses, hipStream_t s) {
     if (a.rowmap && NT != 1) return hipErrorInvalidValue;
@@ -1881,7 +1870,9 @@ hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim,
     } else if (head_dim == 256) {
         hipLaunchKernelGGL((attn_kernel<P, 1, 256>), dim3(nitems * heads), dim3(256), 65536, s, a);
     } else if (head_dim == 64) {             // wav2vec2 body: 12 heads of 64
-        hipLaunchKernelGGL(attn_mixed64_kernel<P>, dim3(nitems * heads), dim3(256), 65536, s, a);
+        // (a kernel holding both tile widths, as at d = 128, allocates 256 registers with spills for the 128-query body
+        // and runs the 64-query one 6 % slower; 128-query tiles themselves measured slower at 16 x 499 frames)
+        hipLaunchKernelGGL((attn_kernel<P, 1, 64>), dim3(nitems * heads), dim3(256), 65536, s, a);
     } else {
         return hipErrorInvalidValue;
     }
