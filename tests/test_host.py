@@ -296,3 +296,31 @@ def test_w2v2fb_engine_cache_is_bound_to_the_model_object(monkeypatch):
     assert any(entry[0] is a for entry in w2v2fb._encoders.values())
     w2v2fb.clear()
     assert not w2v2fb._encoders and not w2v2fb._bodies and not w2v2fb._models
+
+
+def test_hot_kernels_do_not_wait_for_store_acknowledgements():
+    """hipcc's wait-count insertion across control flow puts `s_waitcnt vmcnt(0)` behind stores -- the
+    wave then waits for the store's ACKNOWLEDGEMENT (300 cycles per store instruction in ppg_gemm32.hip's epilogue
+    before it was restructured).  tools/wait_scan.py counts, per kernel of the built library, the vmcnt(0) waits that
+    follow a store; the kernels of the benchmarked paths have a budget (what is left: phase ends, the irregular-tile
+    path of the Q/K/V tail).  A compiler upgrade or an edit that re-introduces the pattern fails here."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    library = os.path.join(root, 'ppgs_amd', 'libppgs_amd.so')
+    if not os.path.exists(library) or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no built library / llvm-objdump')
+    spec = importlib.util.spec_from_file_location('wait_scan', os.path.join(root, 'tools', 'wait_scan.py'))
+    wait_scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wait_scan)
+    kernels = wait_scan.scan(library)
+    budget = {
+        'layer32_kernel<PrecBF16, 256, true, 5>': 4, 'layer32_kernel<PrecBF16, 256, false, 5>': 0,
+        'head32_kernel<PrecBF16, 5>': 12, 'attn_mixed_kernel<PrecBF16>': 2, 'outconv_kernel<PrecBF16>': 0,
+        'gemm32_kernel<PrecBF16, 4, 0>': 0, 'gemm32_kernel<PrecBF16, 4, 1>': 0, 'gemm32_kernel<PrecBF16, 5, 3>': 0,
+        'posconv_kernel<PrecBF16>': 0, 'w2v2_layernorm_kernel<PrecBF16, 768>': 0,
+        'linear_kernel<PrecBF16, 1, 16, 1>': 1, 'ffn32x2_kernel<true, true>': 3,
+    }
+    for name, allowed in budget.items():
+        assert name in kernels, name
+        assert kernels[name]['vmcnt0_after_store'] <= allowed, (name, dict(kernels[name]))

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = '/opt/rocm/lib/llvm/bin'
 
 
-def main(path):
+def scan(path):
+    """{demangled kernel name: Counter(stores, vmcnt0, vmcnt0_after_store)} of the gfx950 code objects in `path`."""
     tmp = tempfile.mkdtemp()
     try:
         local = os.path.join(tmp, 'lib.so')
@@ -54,12 +55,16 @@ def main(path):
             if kernel:
                 rows.append((kernel, stats))
         demangle = subprocess.run(['c++filt'], input='\n'.join(k for k, _ in rows), capture_output=True, text=True).stdout.splitlines()
-        for (kernel, stats), nice in sorted(zip(rows, demangle), key=lambda r: -r[0][1]['vmcnt0_after_store']):
-            if stats['stores']:
-                nice = re.sub(r'\(anonymous namespace\)::', '', nice).split('(')[0]
-                print(f"{stats['vmcnt0_after_store']:4d} of {stats['vmcnt0']:4d} vmcnt(0) waits behind a store, {stats['stores']:4d} stores   {nice[:110]}")
+        return {re.sub(r'\(anonymous namespace\)::', '', nice).split('(')[0].replace('void ', ''): stats
+                for (_, stats), nice in zip(rows, demangle)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main(path):
+    for name, stats in sorted(scan(path).items(), key=lambda item: -item[1]['vmcnt0_after_store']):
+        if stats['stores']:
+            print(f"{stats['vmcnt0_after_store']:4d} of {stats['vmcnt0']:4d} vmcnt(0) waits behind a store, {stats['stores']:4d} stores   {name[:110]}")
 
 
 if __name__ == '__main__':
