@@ -2020,13 +2020,15 @@ int ppg_w2v2_features(PpgW2v2* model, const float* audio, int batch, int64_t sam
 }
 
 // ----------------------------------------------------------------------------
-// wav2vec 2.0 transformer body (include/ppgs_amd.h: ppg_w2v2_body_*).  A first, unfused form on the engine's
-// generic kernels: every projection is linear_kernel<EPI_GENERAL> (bias, GELU, residual in the epilogue), the
-// LayerNorms (width 768 does not fit the GEMM epilogues' register tiles) are w2v2_layernorm_kernel, attention is
-// attn_kernel<.., 1, 64>, the positional convolution is 16 grouped GEMMs of one launch (blockIdx.y = group: taps 128,
-// 48 channels of a group = 1.5 K-groups of 64 bytes in the 16-bit modes, read as 2 with zero weights for the 16
-// channels of the neighbouring group).  Token space: item b owns rows b R .. b R + frames - 1, R = frames rounded
-// up to 32 (no half-written V^T groups); one attention window per item, keys limited to its valid frames.
+// wav2vec 2.0 transformer body (include/ppgs_amd.h: ppg_w2v2_body_*): HF Wav2Vec2FeatureProjection,
+// Wav2Vec2PositionalConvEmbedding and 12 post-norm encoder layers, one launch per GEMM (a fused layer at
+// hidden 768 is bound by the weights a workgroup would stream).  16-bit modes: every projection (feature projection,
+// Q | K | V, out-proj, FFN-1, FFN-2) on ppg_gemm32.hip with its epilogue fixed per use, the positional convolution on
+// ppg_posconv.hip, LayerNorm-768 as a row kernel, attention as attn_kernel<.., 1, 64> (12 heads of 64).  fp32 mode (and
+// the PPGS_AMD_W2V2_* = 0 switches): the same sequence on linear_kernel<EPI_QKV / EPI_GENERAL> (bias, GELU, residual
+// in the epilogue; the positional convolution as 16 grouped k-tap GEMMs of one launch).  Token space: item b owns rows
+// b R .. b R + frames - 1, R = frames rounded up to 32 (no half-written V^T groups); one attention window per item,
+// keys limited to its valid frames.  Batches of >= 8 items run as two half-batches on two HIP streams.
 // ----------------------------------------------------------------------------
 struct PpgW2v2Body {
     PpgEngine eng;

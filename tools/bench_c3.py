@@ -90,7 +90,7 @@ def main():
         body_flops = 16 * frames * (2 * 512 * 768 + 2 * 48 * 128 * 768 + 12 * (8 * 768 * 768 + 4 * 768 * 3072 + 4 * frames * 768))
         body_hip_ms = timed(lambda: body(extract, [frames] * 16))
         record['w2v2_transformer_hip'] = {'ms': body_hip_ms, 'tflops': body_flops / body_hip_ms / 1e9, 'flops': body_flops,
-                                          'what': 'feature projection + positional convolution + 12 layers (engine.W2v2Body, unfused first form)'}
+                                          'what': 'feature projection + positional convolution + 12 layers (engine.W2v2Body: one launch per GEMM on ppg_gemm32.hip, ppg_posconv.hip)'}
         record['feature_encoder_hip'] = {'ms': hip_ms, 'tflops': conv_flops / hip_ms / 1e9, 'flops': conv_flops}
         record['feature_encoder_pytorch_fp32'] = {'ms': torch_ms, 'tflops': conv_flops / torch_ms / 1e9}
         record['w2v2_transformer_pytorch_fp32'] = {'ms': body_ms}
