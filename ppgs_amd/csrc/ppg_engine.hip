@@ -908,8 +908,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (cfg->precision != PPG_PRECISION_FP32 && cfg->precision != PPG_PRECISION_BF16 && cfg->precision != PPG_PRECISION_FP16 &&
         cfg->precision != PPG_PRECISION_FP16X2)
         return fail(PPG_EINVAL, "precision %d", cfg->precision);
-    if (cfg->precision == PPG_PRECISION_FP16X2 && (H != 256 || dh != 128 || F % 64))
-        return fail(PPG_EINVAL, "the fp16x2 mode covers hidden 256 with head dimension 128 (hidden %d, head dimension %d)", H, dh);
+    if (cfg->precision == PPG_PRECISION_FP16X2 && !((H == 256 && dh == 128) || (H == 512 && dh == 256)))
+        return fail(PPG_EINVAL, "the fp16x2 mode covers hidden 256 with head dimension 128 and hidden 512 with head dimension 256 (hidden %d, head dimension %d)", H, dh);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(PPG_EDEVICE, "no HIP device: the PPG engine has no CPU path");
@@ -966,6 +966,9 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (e->split) {
         // the unfused launch sequence: Q/K/V, attention, out-projection + LayerNorm, FFN as one launch each
         e->op_fused = false; e->qkv_fused = false; e->ffn_mixed = false; e->ffn_fused = true;
+        // hidden 512: the FFN as two GEMMs through a [tokens][ffn] buffer of [32 hi | 32 lo] rows (a chunk of the fused
+        // kernel cannot hold a 32-wide hidden group of both weight tiles: ppg_kernels.hip, launch_linear_x2_nt)
+        if (H == 512) e->ffn_fused = false;
     }
     if (!e->layer32 || H != 256 || e->Cp != 96 || !e->qkv_fused) e->head32 = false;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
@@ -1557,6 +1560,7 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     if (max_frames < 1 || max_frames > e->cfg.chunk_length)
         return fail(PPG_ELENGTH, "max_frames %d outside [1, %d] (one window)", max_frames, e->cfg.chunk_length);
     if (feature_dtype != PPG_DTYPE_F16 && feature_dtype != PPG_DTYPE_F32) return fail(PPG_EINVAL, "feature dtype %d", feature_dtype);
+    if (e->split && !e->ffn_fused) return fail(PPG_EINVAL, "the fp16x2 mode has no KV-cached stream at hidden %d", e->cfg.hidden_channels);
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_OK(hipSetDevice(e->device));
     std::unique_ptr<PpgStream> st(new PpgStream);

@@ -686,7 +686,10 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
             for (int nb = 0; nb < NB; ++nb) {
                 const int n = n0 + nb * 16 + 4 * g;
                 const float4 bv = *reinterpret_cast<const float4*>(lbias + nb * 16 + 4 * g);
-                store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes,
+                // (split operands: the hi plane's place of the element inside its [32 hi | 32 lo] block)
+                char* dst = a.out_rows + (size_t)m * a.out_ld * P::kBytes;
+                if constexpr (P::kSplit) dst += P::row_byte(n); else dst += (size_t)n * P::kBytes;
+                store4<P>(dst,
                           fmaxf(acc[nb][t][0] + bv.x, 0.f), fmaxf(acc[nb][t][1] + bv.y, 0.f),
                           fmaxf(acc[nb][t][2] + bv.z, 0.f), fmaxf(acc[nb][t][3] + bv.w, 0.f));
             }
@@ -1445,11 +1448,18 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
 // matching key order of V^T is produced by the QKV epilogue.  Row max/sum
 // over keys = per-lane partials + shuffles over the 4 lane groups.
 // ---------------------------------------------------------------------------
+// Bytes of one K (and one V^T) tile of the attention kernels (four of them in LDS: two DMA double buffers)
+template <class P, int DH>
+constexpr int attn_tile_bytes() { return (P::kSplit && DH == 256) ? 32768 : 16384; }
+
 template <class P, int NTQ, int DH, int NW>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& item, const int head, char* smem) {
     constexpr int ROWK = DH * P::kBytes;            // K tile row bytes
     constexpr int DG = ROWK / 64;                   // K-groups over head dim
-    constexpr int KT = 16384 / ROWK;                // keys per tile
+    // bytes of a K tile and of a V^T tile: 16 KiB; split operands at d = 256: 32 KiB, so that a tile holds a
+    // whole [32 hi | 32 lo] group of keys (one workgroup per CU: 128 KiB of tile buffers)
+    constexpr int TB = attn_tile_bytes<P, DH>();
+    constexpr int KT = TB / ROWK;                   // keys per tile
     constexpr int KB = KT / 16;                     // key 16-blocks per tile
     constexpr int ROWV = KT * P::kBytes;            // V^T tile row bytes (128 or 64)
     constexpr int PG = ROWV / 64;                   // K-groups of PV per tile
@@ -1488,14 +1498,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     const char* kbase = a.qk + (size_t)w.tok_off * a.qk_ld_bytes + ((size_t)a.H + (size_t)head * DH) * P::kBytes;
     const char* vbase = a.vt + (size_t)head * DH * a.vt_ld_bytes + (size_t)w.vt_off * P::kBytes;
 
-    // LDS: K tiles at 0 / 16 KiB, V^T tiles at 32 / 48 KiB (DMA double buffers).
+    // LDS: K tiles at 0 / TB, V^T tiles at 2 TB / 3 TB (DMA double buffers).
     // K runs one tile ahead of V: the scores of tile kt+1 are computed while
     // the softmax of tile kt runs (see the loop).
     auto stage_k = [&](int kt) {
-        stage_tile<KT, ROWK, NW>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, smem + (kt & 1) * 16384, wave, lane);
+        stage_tile<KT, ROWK, NW>(kbase + (size_t)kt * KT * a.qk_ld_bytes, (size_t)a.qk_ld_bytes, smem + (kt & 1) * TB, wave, lane);
     };
     auto stage_v = [&](int kt) {
-        stage_tile<DH, ROWV, NW>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, smem + 32768 + (kt & 1) * 16384, wave, lane);
+        stage_tile<DH, ROWV, NW>(vbase + (size_t)kt * ROWV, (size_t)a.vt_ld_bytes, smem + 2 * TB + (kt & 1) * TB, wave, lane);
     };
 
     f32x4 oacc[DB][NTQ];
@@ -1518,13 +1528,13 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     for (int t = 0; t < NTQ; ++t) { shift[t] = 0.f; lrun[t] = 0.f; cinit[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const uint32_t lds0 = lds_addr(smem);
-    constexpr int NSTEP = DG * KB;              // fragments of a K tile (16 KiB / 1 KiB)
+    constexpr int NSTEP = DG * KB;              // fragments of a K tile (TB / 1 KiB)
     // S^T = K q^T - shift of tile kt into s (fragment i = (kg, kb) = (i / KB, i % KB));
     // `filler(step)` is VALU work issued between the MFMAs
     auto scores = [&](int kt, f32x4 (&s)[KB][NTQ], auto filler) {
         using LK = FragLayout<ROWK, KB>;
         uint32_t fbk[LK::VAR];
-        LK::bases(lds0 + (kt & 1) * 16384, idx, g, fbk);
+        LK::bases(lds0 + (kt & 1) * TB, idx, g, fbk);
         lds_stream<LK, NSTEP, 6>(fbk, [&](auto ic, const u32x4& kf) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -1688,7 +1698,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         stamp(kt, 2);
         using LV = FragLayout<ROWV, DB>;
         uint32_t fbv[LV::VAR];
-        LV::bases(lds0 + 32768 + (kt & 1) * 16384, idx, g, fbv);
+        LV::bases(lds0 + 2 * TB + (kt & 1) * TB, idx, g, fbv);
         lds_stream<LV, PG * DB, 6>(
             fbv,
             [&](auto ic, const u32x4& vf) {
@@ -1879,14 +1889,21 @@ hipError_t launch_attn_p(const AttnArgs& a, int nitems, int heads, int head_dim,
     return hipGetLastError();
 }
 
-// Split-precision operands (PrecX2): the token-split kernels of the unfused launch sequence at hidden 256
+// Split-precision operands (PrecX2): the token-split kernels of the unfused launch sequence.  Hidden 256: Q/K/V,
+// attention, out-projection + LayerNorm, the fused FFN.  Hidden 512 (head dimension 256): the FFN as two GEMMs
+// (linear-1 + ReLU into [32 hi | 32 lo] rows, linear-2 + residual + LayerNorm) -- a chunk of the fused FFN kernel
+// would have to hold a whole 32-wide hidden group of both weight tiles, 2 x 2 x 64 KiB of LDS.
 template <int NT>
 hipError_t launch_linear_x2_nt(int epi, int nb, const LinearArgs& a, int ypasses, hipStream_t s) {
     switch (epi) {
     case EPI_INCONV:  return launch_linear_t<PrecX2, NT, 16, EPI_INCONV>(a, ypasses, s);
     case EPI_QKV:     return launch_linear_t<PrecX2, NT, 16, EPI_QKV>(a, ypasses, s);
+    case EPI_RELU:    return launch_linear_t<PrecX2, NT, 16, EPI_RELU>(a, ypasses, s);
     case EPI_OUTCONV: return launch_linear_t<PrecX2, NT, 3, EPI_OUTCONV>(a, ypasses, s);
-    case EPI_RESLN:   return nb == 16 ? launch_linear_t<PrecX2, 1, 16, EPI_RESLN>(a, ypasses, s) : hipErrorInvalidValue;
+    case EPI_RESLN:
+        if (nb == 16) return launch_linear_t<PrecX2, 1, 16, EPI_RESLN>(a, ypasses, s);
+        if (nb == 32) return launch_linear_t<PrecX2, 1, 32, EPI_RESLN>(a, ypasses, s);
+        return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
@@ -1973,6 +1990,15 @@ hipError_t launch_attn(int precision, const AttnArgs& args, int nitems, int head
     if (precision == PPG_PRECISION_BF16) return launch_attn_p<PrecBF16>(a, nitems, heads, head_dim, s);
 #if PPG_X2
     if (precision == PPG_PRECISION_FP16X2) {
+        if (head_dim == 256) {       // 32-key tiles of 32 KiB (attn_tile_bytes): one workgroup per CU
+            auto kern = attn_kernel<PrecX2, 1, 256>;
+            constexpr size_t lds = 4 * attn_tile_bytes<PrecX2, 256>();
+            static ppg::LdsLimit limit;
+            const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(nitems * heads), dim3(256), lds, s, a);
+            return hipGetLastError();
+        }
         if (head_dim != 128) return hipErrorInvalidValue;
         hipLaunchKernelGGL(attn_mixed_kernel<PrecX2>, dim3(nitems * heads), dim3(256), 65536, s, a);
         return hipGetLastError();

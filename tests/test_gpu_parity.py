@@ -1500,8 +1500,38 @@ def test_fp16x2_mode_meets_the_fp32_bar(golden):
     assert np.abs(ppg[0, :, :64].numpy() - g6['ppg_item0_first64']).max() < FP32_TOL
     assert np.abs(ppg[31, :, -64:].numpy() - g6['ppg_item31_last64']).max() < FP32_TOL
     assert np.abs(ppg.mean(-1).numpy() - g6['ppg_mean']).max() < FP32_TOL
+
+
+def test_fp16x2_mode_at_hidden_512(golden):
+    """fp16x2 at the w2v2fb geometry (768 input channels, hidden 512, two heads of 256): attention on 32-key tiles of
+    32 KiB (a tile holds a whole [32 hi | 32 lo] group), the FFN as two GEMMs through [32 hi | 32 lo] rows.  The
+    reference fixture G5 and ragged / chunked / causal batches against the oracle, all at the fp32 bar; the
+    KV-cached stream is refused in this combination, and so are geometries outside the two the mode covers."""
+    wide, state = eng(seed=55, cin=768, hidden=512, precision='fp16x2')
+    g5 = golden('g5_w2v2fb')
+    ppg = run(wide, g5['features'], g5['lengths'])
+    assert np.abs(ppg - g5['ppg']).max() < FP32_TOL
+    assert np.allclose(ppg.sum(1), 1, atol=1e-5)
+    gen = torch.Generator().manual_seed(29)
+    for T, lengths in ((501, [501, 0, 33]), (850, [850, 400, 17, 849]), (64, [64, 1]), (499, [499] * 16)):
+        feats = torch.randn(len(lengths), 768, T, generator=gen).half()
+        ref = O.from_features(state, feats.float(), torch.tensor(lengths)).numpy()
+        out = run(wide, feats.numpy(), lengths)
+        assert np.isfinite(out).all()
+        assert np.abs(out - ref).max() < FP32_TOL, (T, lengths)
+    # sharpened posteriors (up to 0.5+), where plain fp16 operands are 3e-3 off
+    sharp, sharp_state = eng(seed=56, sharpen=2.0, cin=768, hidden=512, precision='fp16x2')
+    feats = torch.randn(3, 768, 300, generator=gen).half()
+    ref = O.from_features(sharp_state, feats.float(), torch.tensor([300, 150, 299])).numpy()
+    assert np.abs(run(sharp, feats.numpy(), [300, 150, 299]) - ref).max() < FP32_TOL
+    causal, causal_state = eng(seed=55, cin=768, hidden=512, precision='fp16x2', causal=True)
+    feats = torch.randn(2, 768, 200, generator=gen).half()
+    ref = O.from_features(causal_state, feats.float(), torch.tensor([200, 77]), is_causal=True).numpy()
+    assert np.abs(run(causal, feats.numpy(), [200, 77]) - ref).max() < FP32_TOL
     with pytest.raises((ValueError, E.PpgError)):
-        E.Engine(W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512), 0, 'fp16x2')
+        causal.stream(100)
+    with pytest.raises((ValueError, E.PpgError)):       # hidden 512 as four heads of 128: not covered
+        E.Engine(W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512), 0, 'fp16x2', heads=4)
 
 
 def test_fp16x2_feature_split_ffn_vs_token_split_and_oracle(monkeypatch):
