@@ -44,8 +44,9 @@ enum {
     PPG_PRECISION_FP16X2 = 3, /* fp32 values as two fp16 halves (hi + lo), a product as three fp16 MFMAs with
                                fp32 accumulation: fp32-grade operands (22 significand bits; <= 1e-4 vs the
                                reference's fp32 forward -- the autocast-off route of ppgs/core.py:586-594)
-                               at a third of the fp16 MFMA rate, 5x the f32-input MFMA rate.  mel-sized
-                               models (hidden 256, head dimension 128); magnitudes below 65504 as fp16   */
+                               at a third of the fp16 MFMA rate, 5x the f32-input MFMA rate.  Hidden 256 with
+                               head dimension 128 (mel-sized models) and hidden 512 with head dimension 256
+                               (the w2v2fb network; no KV-cached stream there); magnitudes below 65504 as fp16   */
 };
 
 /* dtype tags for feature tensors handed to ppg_encode */

@@ -39,6 +39,13 @@ def main():
         model = E.Engine(state, 0, precision)
         outputs[precision] = model.encode(feats, lengths).float().cpu()
         record['ms_per_step'][precision] = timed(lambda: model.encode(feats, lengths))
+        if precision == 'fp16x2':       # HIP-event time per kernel class (profile mode serialises the two pipelines' launches)
+            model.profile(True)
+            for _ in range(5):
+                model.encode(feats, lengths)
+            torch.cuda.synchronize()
+            record['fp16x2_kernel_ms_per_step_stream_summed'] = {n: v[0] / 5 for n, v in model.profile_read().items()}
+            model.profile(False)
         del model
     reference = O.from_features(state, feats[:2].cpu().float(), torch.tensor(lengths[:2]))
     record['max_abs_vs_oracle_2_utterances'] = {p: float((o[:2] - reference).abs().max()) for p, o in outputs.items()}
