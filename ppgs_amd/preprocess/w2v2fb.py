@@ -51,16 +51,24 @@ def model_for(device):
     return _models[key]
 
 
+def w2v2_precision():
+    """Operand precision of the wav2vec2 engines for the package's PRECISION: they have fp32 and 16-bit forms only,
+    so 'fp16x2' (every PPG-network operand an fp16 hi + lo pair, <= 1e-4) runs them in their own <= 1e-4 form,
+    fp32 -- the whole w2v2fb path then stays inside the parity bar, with the PPG network at a third of its fp32 time."""
+    from .. import core
+    return 'fp32' if core.PRECISION == 'fp16x2' else core.PRECISION
+
+
 def feature_encoder_for(device, model):
     """Cached HIP feature encoder holding `model`'s convolution weights."""
-    from .. import core, engine
-    key = (str(device), id(model), core.PRECISION)
+    from .. import engine
+    key = (str(device), id(model), w2v2_precision())
     entry = _encoders.get(key)
     # (the entry keeps the model alive: the id of a freed model can be handed to the next one, and an engine found
     # under it would hold the OLD model's weights)
     if entry is None or entry[0] is not model:
         entry = _encoders[key] = (model, engine.W2v2FeatureEncoder(
-            model.feature_extractor.state_dict(), device.index, core.PRECISION))
+            model.feature_extractor.state_dict(), device.index, w2v2_precision()))
     return entry[1]
 
 
@@ -69,11 +77,11 @@ _bodies = {}
 
 def body_for(device, model):
     """Cached HIP transformer body holding `model`'s projection / encoder weights."""
-    from .. import core, engine
-    key = (str(device), id(model), core.PRECISION)
+    from .. import engine
+    key = (str(device), id(model), w2v2_precision())
     entry = _bodies.get(key)
     if entry is None or entry[0] is not model:
-        entry = _bodies[key] = (model, engine.W2v2Body(model, device.index, core.PRECISION))
+        entry = _bodies[key] = (model, engine.W2v2Body(model, device.index, w2v2_precision()))
     return entry[1]
 
 
@@ -90,7 +98,6 @@ def last_hidden_state(model, padded, mask):
     attention mask -> feature_projection -> encoder."""
     if os.environ.get('PPGS_AMD_W2V2_NATIVE', '1') == '0':
         return model(padded, mask).last_hidden_state
-    from .. import core
     extract = feature_encoder_for(padded.device, model)(padded)
     attention_mask = model._get_feature_vector_attention_mask(
         extract.shape[1], mask, add_adapter=False)
@@ -101,7 +108,7 @@ def last_hidden_state(model, padded, mask):
     # PPGS_AMD_W2V2_BODY=0: the HF modules on PyTorch-ROCm; in the 16-bit engine modes under fp16
     # autocast, which is how the reference itself runs the whole model on a GPU
     # (ppgs/preprocess/core.py:207: torch.autocast('cuda')); fp32 engine mode: fp32 throughout
-    with torch.autocast('cuda', dtype=torch.float16, enabled=core.PRECISION != 'fp32'):
+    with torch.autocast('cuda', dtype=torch.float16, enabled=w2v2_precision() != 'fp32'):
         hidden, _ = model.feature_projection(extract)
         out = model.encoder(hidden, attention_mask=attention_mask).last_hidden_state
     return out.float()

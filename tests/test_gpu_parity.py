@@ -931,6 +931,37 @@ def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
     w2v2fb.clear()
 
 
+def test_c3_w2v2fb_fp16x2_route(monkeypatch):
+    """configs[2] with PRECISION = 'fp16x2': the wav2vec2 engines have fp32 and 16-bit forms only, so the route runs
+    them in fp32 (their <= 1e-4 form: the latents ARE the fp32 mode's) and the hidden-512 PPG network on fp16 hi + lo
+    operands -- the posteriors stay within 1e-4 of the oracle on the same latents."""
+    monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
+    from ppgs_amd.preprocess import w2v2fb
+    w2v2fb.clear()
+    gen = torch.Generator().manual_seed(5)
+    audio = 0.1 * torch.randn(2, 1, 16000, generator=gen)
+    lengths = torch.tensor([16000, 11200])
+    audio[1, :, 11200:] = 0
+    old = ppgs_amd.core.PRECISION
+    try:
+        ppgs_amd.core.PRECISION = 'fp32'
+        reference_feats = w2v2fb.from_audios(audio, lengths, gpu=0).clone()
+        ppgs_amd.core.PRECISION = 'fp16x2'
+        assert w2v2fb.w2v2_precision() == 'fp32'
+        feats = w2v2fb.from_audios(audio, lengths, gpu=0)
+    finally:
+        ppgs_amd.core.PRECISION = old
+    assert feats.shape == (2, 768, 100) and feats.dtype == torch.float16
+    assert torch.equal(feats, reference_feats)
+    state = W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512)
+    engine = E.Engine(state, 0, 'fp16x2')
+    frames = lengths // 160
+    ppg = engine.encode(feats, frames).cpu().numpy()
+    oracle = O.from_features(state, feats.cpu(), frames).numpy()
+    assert np.abs(ppg - oracle).max() < FP32_TOL
+    w2v2fb.clear()
+
+
 def test_graphed_encode_helper():
     engine, state = eng(precision='bf16')
     gen = torch.Generator().manual_seed(4)
