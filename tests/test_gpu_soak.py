@@ -6,7 +6,7 @@ runs kernels of its own two pipelines side by side by default, so every victim b
 launches with `torch.nn.functional.scaled_dot_product_attention` hammering a third stream, and every result must be
 bit-identical to the result of the same call on a quiet chip in the one-pipeline configuration:
 
-  * ppg_encode as two pipelines (bf16 and fp16), >= 2000 C2 steps each,
+  * ppg_encode as two pipelines (bf16 and fp16), >= 2000 C2 steps each; the fp16x2 mode at both geometries, 600 steps each,
   * the mel frontend (512-thread workgroups that own their CU),
   * the wav2vec2 body as two pipelines,
   * the batched KV-cached stream step (row-mapped launches).
@@ -74,6 +74,32 @@ def test_soak_encode_two_pipelines_beside_sdpa(monkeypatch, precision):
         bad = soak(lambda: engine.encode(feats, lengths), reference, STEPS, aggressor)
     assert bad == 0, f'{bad} of {STEPS} two-pipeline {precision} steps beside SDPA differ from the quiet one-pipeline result'
     assert aggressor.launched >= STEPS
+
+
+@pytest.mark.parametrize('geometry', ['hidden256', 'hidden512'])
+def test_soak_fp16x2_encode_beside_sdpa(geometry):
+    """The fp16x2 mode's kernels (hi + lo operand planes: ffn32x2 layer kernel, split-precision attention and linear
+    kernels; at hidden 512 the 32-KiB-tile attention and the two-GEMM FFN) beside SDPA on another stream: every step
+    bit-equal to the quiet run.  Its steps are 3 - 5 x the 16-bit ones, so the soak is 600 steps (>= 15 000 launches)."""
+    steps = 600
+    if geometry == 'hidden256':
+        state = W.seeded_state_dict(seed=1234)
+        feats = torch.randn(32, 80, 1000, generator=torch.Generator().manual_seed(78)).half().cuda()
+        lengths = [1000] * 32
+    else:
+        state = W.seeded_state_dict(seed=55, input_channels=768, hidden_channels=512)
+        feats = torch.randn(16, 768, 1000, generator=torch.Generator().manual_seed(79)).half().cuda()
+        lengths = [1000] * 16
+    engine = E.Engine(state, 0, 'fp16x2')
+    reference = engine.encode(feats, lengths).clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(reference).all())
+    aggressor = Aggressor()
+    victim = torch.cuda.Stream()
+    with torch.cuda.stream(victim):
+        bad = soak(lambda: engine.encode(feats, lengths), reference, steps, aggressor)
+    assert bad == 0, f'{bad} of {steps} fp16x2 {geometry} steps beside SDPA differ from the quiet result'
+    assert aggressor.launched >= steps
 
 
 def test_soak_frontend_beside_sdpa():
