@@ -962,6 +962,23 @@ def test_c3_w2v2fb_fp16x2_route(monkeypatch):
     w2v2fb.clear()
 
 
+def test_graphed_encode_at_the_benchmark_size_two_pipelines():
+    """Engine.graphed at 32 x 1000 frames: the capture holds BOTH pipelines of the batch (fork / join across two HIP
+    streams inside ppg_encode); replays equal the eager launches bit for bit, also with new input in the static buffer."""
+    engine, _ = eng(precision='bf16')
+    lengths = [1000] * 32
+    _, info = E.plan_windows(32, 1000, lengths, engine=engine)
+    assert engine.pipelines(info.tokens) == 2
+    gen = torch.Generator().manual_seed(41)
+    run = engine.graphed(32, 1000, lengths)
+    for _ in range(3):
+        feats = torch.randn(32, 80, 1000, generator=gen).half().cuda()
+        reference = engine.encode(feats, lengths).clone()
+        out = run(feats)
+        torch.cuda.synchronize()
+        assert torch.equal(out, reference)
+
+
 def test_graphed_encode_helper():
     engine, state = eng(precision='bf16')
     gen = torch.Generator().manual_seed(4)

@@ -298,6 +298,34 @@ def test_w2v2fb_engine_cache_is_bound_to_the_model_object(monkeypatch):
     assert not w2v2fb._encoders and not w2v2fb._bodies and not w2v2fb._models
 
 
+def test_w2v2fb_engines_follow_the_package_precision(monkeypatch):
+    """The wav2vec2 engines have fp32 and 16-bit forms: PRECISION = 'fp16x2' (<= 1e-4 on fp16 hi + lo operands, PPG
+    network only) builds them in fp32 -- their own <= 1e-4 form -- and every other precision is handed through; the
+    engine caches are keyed on what was built."""
+    import types
+    import torch
+    from ppgs_amd import core, engine
+    from ppgs_amd.preprocess import w2v2fb
+    built = []
+
+    class Fake:
+        def __init__(self, *args):
+            built.append(args[-1])
+    monkeypatch.setattr(engine, 'W2v2FeatureEncoder', Fake)
+    monkeypatch.setattr(engine, 'W2v2Body', Fake)
+    w2v2fb.clear()
+    device = torch.device('cuda', 0)
+    model = types.SimpleNamespace(feature_extractor=types.SimpleNamespace(state_dict=lambda: {}))
+    for precision, expected in (('fp16x2', 'fp32'), ('fp32', 'fp32'), ('fp16', 'fp16'), ('bf16', 'bf16')):
+        monkeypatch.setattr(core, 'PRECISION', precision)
+        assert w2v2fb.w2v2_precision() == expected
+        w2v2fb.feature_encoder_for(device, model)
+        w2v2fb.body_for(device, model)
+    # fp16x2 and fp32 share one pair of engines
+    assert built == ['fp32', 'fp32', 'fp16', 'fp16', 'bf16', 'bf16']
+    w2v2fb.clear()
+
+
 def test_hot_kernels_do_not_wait_for_store_acknowledgements():
     """hipcc's wait-count insertion across control flow puts `s_waitcnt vmcnt(0)` behind stores -- the
     wave then waits for the store's ACKNOWLEDGEMENT (300 cycles per store instruction in ppg_gemm32.hip's epilogue
