@@ -41,7 +41,8 @@ streams; the same bits at this batch): a layer launch is then 128 one-per-CU wor
 beside the other pipeline's kernels, so one launch can reach at most half the chip's
 peak (`frac_of_occupied_cus` prices it against the CUs it occupies); the step as a
 whole is `end_to_end_mfma_frac`, and `alt_single_pipeline` is the same step with
-PPGS_AMD_STREAMS=1, where a launch has the whole chip to itself.
+PPGS_AMD_STREAMS=1, where a launch has the whole chip to itself; `alt_graph_replay` is the
+same step with the encoder's launches as one hipGraph replay (bit-equal; the step is not launch-bound).
 `cpu_baseline` is the CPU oracle (fp32 restatement of the reference path,
 proven equal to the reference modules by tests/test_oracle_golden.py) timed on
 the host cores on the same 32 x 1000 batch, plus its bf16-autocast variant
@@ -397,6 +398,36 @@ def run_c2(args, rank, world, local_rank, use_dist):
                        'max_abs_vs_default': float((s1_out - out).abs().max())}
         del other
 
+    alt_graph = None
+    if rank == 0 and world == 1 and not args.no_alt:
+        # the same step with the encoder's launch sequence (both pipelines, their fork / join) as ONE hipGraph replay
+        # (Engine.graphed; the mel frontend launched in front of it as before).  Reported beside the line, never `value`:
+        # the timed region above is the eager path, whose launches the roofline leg's HIP events can bracket.
+        try:
+            replay = model.graphed(BATCH, FRAMES, lengths)
+
+            def graph_step():
+                return replay(ppgs_amd.preprocess.mel.from_audios(audio))
+            for _ in range(max(args.warmup, 3)):
+                graph_step()
+            start = time.perf_counter()
+            while args.prewarm_s > 0 and time.perf_counter() - start < args.prewarm_s:
+                for _ in range(20):
+                    graph_step()
+                torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            start = time.perf_counter()
+            for _ in range(args.steps):
+                g_out = graph_step()
+            torch.cuda.synchronize()
+            g_elapsed = time.perf_counter() - start
+            alt_graph = {'what': 'encoder as one hipGraph replay per step (Engine.graphed), frontend in front of it',
+                         'ms_per_step': 1e3 * g_elapsed / args.steps, 'value': BATCH * FRAMES * args.steps / g_elapsed,
+                         'max_abs_vs_default': float((g_out - out).abs().max())}
+            del replay
+        except Exception as error:                              # the leg is optional: the line must not depend on it
+            alt_graph = {'skipped': f'{type(error).__name__}: {error}'}
+
     if rank != 0:
         return None
     ms_per_step = 1e3 * elapsed / args.steps
@@ -494,6 +525,8 @@ def run_c2(args, rank, world, local_rank, use_dist):
         alt_streams['roofline_frac_whole_chip'] = (ffn_flops * launches_per_layer / (1e-3 * alt_streams['mean_launch_ms'])
                                                    / 1e12 / peak)
         line['alt_single_pipeline'] = alt_streams
+    if alt_graph:
+        line['alt_graph_replay'] = alt_graph
     if world == 1 and not args.no_cpu:
         line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
         line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
