@@ -70,6 +70,82 @@ PEAK_FP32_TFLOPS = 157.3
 HIDDEN, FFN, LAYERS = 256, 2048, 5
 
 
+# PPGS_AMD_* switches that select a CONFIGURATION of the same computed work (recorded in the line as `env_switches`);
+# every other PPGS_AMD_* variable is an experiment / ablation switch of the engine (kernel selection, phase skipping in
+# debug builds, timing dumps): with one of those set this script refuses to produce a line (--allow-ablation: it
+# prints the line with `value` nulled and the variables under `ablation_env`)
+CONFIG_SWITCHES = {'PPGS_AMD_STREAMS', 'PPGS_AMD_LIB', 'PPGS_AMD_BIND_CPUS', 'PPGS_AMD_SYSFS_ROOT', 'PPGS_AMD_CHECKPOINT'}
+
+
+def env_guard(args):
+    """-> (config switches set, ablation switches set); exits when an ablation switch is set without --allow-ablation"""
+    mine = {k: v for k, v in os.environ.items() if k.startswith('PPGS_AMD_')}
+    config = {k: v for k, v in mine.items() if k in CONFIG_SWITCHES}
+    ablation = {k: v for k, v in mine.items() if k not in CONFIG_SWITCHES}
+    if ablation and not args.allow_ablation:
+        raise SystemExit(f'bench.py: experiment switches are set ({ablation}); a line measured under them is not the '
+                         'benchmark -- unset them, or pass --allow-ablation for a line with `value` nulled')
+    return config, ablation
+
+
+class ClockSampler:
+    """Shader clock of the GPU while a block of steps runs, from the driver's sysfs file (pp_dpm_sclk: the line with
+    the `*` is the current level), read by a thread every few milliseconds; best effort -- None where the container
+    does not show the file.  The 2.5 PF peak is quoted at 2.4 GHz; `mfma_busy_frac` divides by that nominal clock."""
+
+    def __init__(self, device_index):
+        import glob
+        # the card whose PCI address is the torch device's (a box shows every GPU of the node in sysfs, one of them in HIP)
+        self.path = None
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            want = f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}'
+            for path in sorted(glob.glob('/sys/class/drm/card*/device')):
+                if os.path.basename(os.path.realpath(path)).startswith(want) and os.path.exists(path + '/pp_dpm_sclk'):
+                    self.path = path + '/pp_dpm_sclk'
+                    break
+        except (AttributeError, OSError):
+            pass
+        self.samples = []
+        self._stop = False
+        self._thread = None
+
+    def _read(self):
+        import re
+        try:
+            with open(self.path) as f:
+                text = f.read()
+            m = re.search(r'(\d+)\s*Mhz\s*\*', text, re.I)
+            return float(m.group(1)) if m else None
+        except OSError:
+            return None
+
+    def __enter__(self):
+        import threading
+        if self.path is not None:
+            def loop():
+                while not self._stop:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(0.0005)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        ordered = sorted(self.samples)
+        return {'mean_mhz': sum(ordered) / len(ordered), 'min_mhz': ordered[0], 'max_mhz': ordered[-1],
+                'median_mhz': ordered[len(ordered) // 2], 'samples': len(ordered), 'source': self.path}
+
+
 def parse(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
@@ -81,6 +157,9 @@ def parse(argv=None):
     parser.add_argument('--cpu-seconds', type=float, default=20.0,
                         help='budget of the CPU-baseline leg')
     parser.add_argument('--no-cpu', action='store_true')
+    parser.add_argument('--allow-ablation', action='store_true',
+                        help='run although PPGS_AMD_* experiment switches are set; the line then carries them under '
+                             '`ablation_env` and its `value` is null')
     parser.add_argument('--no-alt', action='store_true', help='skip the fp16-operand leg of c2')
     parser.add_argument('--prewarm-s', type=float, default=1.0,
                         help='c2: seconds of the same step run untimed after the W warm-up steps and before the '
@@ -155,7 +234,7 @@ def cpu_baseline(state, seconds):
     }
 
 
-def pmc_summary(suffix=''):
+def pmc_summary(suffix='', precision='bf16'):
     """The committed rocprofv3 PMC summary of THIS build: profiles/r*_pmc_summary<suffix>.txt whose `# lib_sha256_16=` header
     equals the sha256 of the library this process loaded (tests/pmc_summary.py writes it; a clean `make` reproduces
     the library byte for byte).  PMC counters cannot be read inside this process, so the figures are never of the
@@ -163,9 +242,8 @@ def pmc_summary(suffix=''):
     -> ({kernel: {counter: mean per dispatch, 'dispatches': n}}, file) or (None, reason)."""
     import glob
     import re
-    from tests.pmc_summary import library_sha16
     from ppgs_amd import engine as E
-    sha = library_sha16(E._LIB_PATH)
+    sha = E.library_sha16()
     seen = []
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_summary{suffix}.txt')), reverse=True):
         with open(path) as f:
@@ -173,6 +251,13 @@ def pmc_summary(suffix=''):
         m = re.search(r'^# lib_sha256_16=([0-9a-f]+)', text, re.M)
         seen.append(f'{os.path.basename(path)}:{m.group(1) if m else "unlabelled"}')
         if not m or m.group(1) != sha:
+            continue
+        # the counters are of ONE arithmetic mode (`# precision=`; summaries older than the header: bf16, or fp16x2 by
+        # their file name): a step of another mode runs other kernels for other durations
+        mode = re.search(r'^# precision=(\w+)', text, re.M)
+        mode = mode.group(1) if mode else ('fp16x2' if 'fp16x2' in suffix else 'bf16')
+        if mode != precision:
+            seen[-1] += f'(precision {mode})'
             continue
         kernels = {}
         for line in text.splitlines():
@@ -316,6 +401,10 @@ def run_c2(args, rank, world, local_rank, use_dist):
     model.profile(False)
     # two more blocks of the same K steps: how much the figure moves from block to block
     repeats = [1e3 * timed_block()[0] / args.steps for _ in range(2)]
+    # the shader clock while the same block of steps runs once more (untimed; a sampler thread reads sysfs)
+    with ClockSampler(local_rank) as sampler:
+        timed_block()
+    clock = sampler.summary()
     # untimed extra pass: per-kernel-class breakdown (events around every launch)
     breakdown_steps = 5
     model.profile(True)
@@ -366,7 +455,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
                   'max_abs_vs_fp16': float((x2_out - alt_out).abs().max())}
         # matrix-pipe busy cycles of an fp16x2 step (three MFMAs per product) from the committed PMC pass of this build
         # with --precision fp16x2, over 4 pipes x CUs x this leg's step time at the nominal 2.4 GHz
-        x2_pmc, x2_from = pmc_summary('_fp16x2')
+        x2_pmc, x2_from = pmc_summary('_fp16x2', 'fp16x2')
         x2_busy = pmc_mfma_busy(x2_pmc) if x2_pmc else None
         alt_x2['mfma_busy_cycles_per_step'] = x2_busy
         alt_x2['mfma_busy_frac'] = (x2_busy / (4.0 * torch.cuda.get_device_properties(local_rank).multi_processor_count
@@ -446,7 +535,7 @@ def run_c2(args, rank, world, local_rank, use_dist):
     launch_cus = min(launch_workgroups, cus) if launch_workgroups else cus
     launch_peak = peak * launch_cus / cus
     layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
-    pmc, pmc_from = pmc_summary('_fp16x2' if args.precision == 'fp16x2' else '')
+    pmc, pmc_from = pmc_summary('_fp16x2' if args.precision == 'fp16x2' else '', args.precision)
     traffic = pmc_traffic(pmc, 'layer32_' if layer32 else 'ffn_') if pmc else None
     mfma_busy = pmc_mfma_busy(pmc) if pmc else None
     kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
@@ -511,6 +600,13 @@ def run_c2(args, rank, world, local_rank, use_dist):
         # of this build) over 4 pipes x CUs x the step's duration at the nominal 2.4 GHz the 2.5 PF peak is quoted at
         'mfma_busy_cycles_per_step': mfma_busy,
         'mfma_busy_frac': mfma_busy / (4.0 * cus * ms_per_step * 2.4e6) if mfma_busy else None,
+        # the shader clock sampled while one more block of the same K steps ran, and the same busy cycles over the
+        # cycles that clock DELIVERED in a step (the pipes are busier than the nominal-clock fraction says when the chip
+        # runs below 2.4 GHz)
+        'shader_clock_under_load': clock,
+        'mfma_busy_frac_of_delivered_cycles': (mfma_busy / (4.0 * cus * ms_per_step * 1e3 * clock['mean_mhz'])
+                                               if mfma_busy and clock else None),
+        'env_switches': args.env_config,
         'repeat_blocks_ms_per_step': repeats,
         'h2d_ms': copies['h2d_ms'],
         'd2h_ms': copies['d2h_ms'],
@@ -530,6 +626,10 @@ def run_c2(args, rank, world, local_rank, use_dist):
     if world == 1 and not args.no_cpu:
         line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
         line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']
+    if args.env_ablation:
+        line['ablation_env'] = args.env_ablation
+        line['value_under_ablation'] = line['value']
+        line['value'] = None
     return line
 
 
@@ -728,6 +828,7 @@ def _spawned(local_rank, args, port):
 
 def main():
     args = parse()
+    args.env_config, args.env_ablation = env_guard(args)
     if 'RANK' in os.environ or args.gpus == 1:
         rank_main(args)                  # launched by torch.distributed.run (or a single rank)
         return

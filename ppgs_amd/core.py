@@ -4,9 +4,12 @@ from_file_to_file :171, from_files_to_files :207, from_dataloader :280,
 infer :551, resample :599), executed by the HIP engine.
 
 Differences that a drop-in user should know (also in INTEGRATION.md):
-* ``gpu=None`` means "the current HIP device" (the reference runs on the CPU
-  there); this engine has no CPU path and raises if no GPU is visible.
-* Outputs are fp32 posteriors on the selected GPU, layout (batch, 40, frames).
+* ``gpu=None`` computes on the current HIP device (the reference runs on the
+  CPU there); this engine has no CPU path and raises if no GPU is visible.  What
+  the CALLER sees is the reference's: host tensors in + ``gpu=None`` -> a host
+  tensor out (reference core.py:106: device 'cpu'); a tensor that is already on
+  a HIP device, or an explicit ``gpu=``, -> the result stays on that device.
+* Outputs are fp32 posteriors, layout (batch, 40, frames).
 * ``from_audio`` accepts batch > 1 (all rows full length); the reference
   raises there (core.py:60).
 """
@@ -96,14 +99,16 @@ def from_audio(audio, sample_rate, representation=config.REPRESENTATION,
 
     audio (batch, 1, samples) -> (batch, 40, samples // 160)
     """
+    to_host = gpu is None and not audio.is_cuda      # (the reference's gpu=None returns a CPU tensor)
     features = preprocess.from_audio(
         audio=audio, sample_rate=sample_rate, representation=representation,
         gpu=gpu)
     lengths = torch.full(
         (features.shape[0],), features.shape[-1], dtype=torch.long)
-    return from_features(
+    result = from_features(
         features=features, lengths=lengths, representation=representation,
         checkpoint=checkpoint, gpu=gpu, legacy_mode=legacy_mode)
+    return result.cpu() if to_host else result
 
 
 def from_features(features, lengths, representation=config.REPRESENTATION,
@@ -113,11 +118,13 @@ def from_features(features, lengths, representation=config.REPRESENTATION,
     features (batch, channels, frames), lengths (batch,) ->
     (batch, 40, frames) posteriors (logits when softmax=False)
     """
+    to_host = gpu is None and not features.is_cuda
     device = device_for(gpu, features)
-    return infer(
+    result = infer(
         features=features.to(device), lengths=lengths,
         representation=representation, checkpoint=checkpoint,
         softmax=softmax, legacy_mode=legacy_mode)
+    return result.cpu() if to_host else result
 
 
 def from_file(file, representation=config.REPRESENTATION, checkpoint=None,

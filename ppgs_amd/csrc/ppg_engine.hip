@@ -276,6 +276,7 @@ struct PpgEngine {
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
+    bool attn64 = false;     // whole-batch attention on ppg_attn64.hip (head dimension 128, 16-bit modes; PPGS_AMD_ATTN64=0: attn_mixed_kernel)
     unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
     int ffn32x2 = 3;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 3 = out-proj + LN1 + FFN + LN2 + the next layer's Q/K/V in ONE feature-split launch per layer (ppg_ffn32x2.hip), 2 = without the Q/K/V tail, 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
     bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
@@ -558,8 +559,11 @@ int group_count(const PpgEngine* e, int tokens) {
     return tokens >= e->stream_min_rows * e->num_cus ? e->num_streams : 1;
 }
 
+// Queries per attention workgroup of the encoder's whole-batch launches
+int plan_qtile(const PpgEngine* e) { return e->attn64 ? ppg::attn64_query_tile() : ppg::attn_query_tile(e->head_dim); }
+
 size_t finish_plan(const PpgEngine* e, Plan* p) {
-    split_groups(p, group_count(e, p->info.tokens), ppg::attn_query_tile(e->head_dim), e->attn_xcd ? e->cfg.heads : 0, e->attn_narrow && e->head_dim == 128);
+    split_groups(p, group_count(e, p->info.tokens), plan_qtile(e), e->attn_xcd ? e->cfg.heads : 0, e->attn_narrow && e->head_dim == 128 && !e->attn64);
     size_t off = 0;
     for (PlanGroup& grp : p->groups) {
         grp.ws_offset = off;
@@ -604,7 +608,7 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
         return fail(PPG_EINVAL, "ppg_encode under stream capture needs a cached plan: run the same (batch, frames, lengths) once before capturing");
     auto dp = std::make_unique<DevPlan>();
     int rc = build_plan(e->cfg.chunk_length, e->cfg.chunk_overlap, e->cfg.max_positions, batch, frames,
-                        lengths, legacy, ppg::attn_query_tile(e->head_dim), &dp->host);
+                        lengths, legacy, plan_qtile(e), &dp->host);
     if (rc) return rc;
     Plan& p = dp->host;
     finish_plan(e, &p);
@@ -954,6 +958,8 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
+    e->attn64 = e->head_dim == 128 && (cfg->precision == PPG_PRECISION_BF16 || cfg->precision == PPG_PRECISION_FP16);
+    if (const char* v = getenv("PPGS_AMD_ATTN64")) e->attn64 = e->attn64 && atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_SUBTILE")) e->subtile = atoi(v) != 0;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), 256));
@@ -961,8 +967,10 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     e->x16 = cfg->precision == PPG_PRECISION_BF16;
     if (const char* v = getenv("PPGS_AMD_X16")) e->x16 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_OUTCONV")) e->outconv = atoi(v) != 0;
+#ifdef PPG_DEBUG_MODES
     if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) e->l32_debug = atoi(v);
     if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) e->h32_debug = atoi(v);
+#endif
     if (e->split) {
         // the unfused launch sequence: Q/K/V, attention, out-projection + LayerNorm, FFN as one launch each
         e->op_fused = false; e->qkv_fused = false; e->ffn_mixed = false; e->ffn_fused = true;
@@ -1197,7 +1205,7 @@ int ppg_plan_windows(const PpgEngine* engine, int batch, int frames, const int64
     const int chunk = engine ? engine->cfg.chunk_length : 500;
     const int overlap = engine ? engine->cfg.chunk_overlap : 50;
     const int maxpos = engine ? engine->cfg.max_positions : 5000;
-    const int qt = ppg::attn_query_tile(engine ? engine->head_dim : 128);
+    const int qt = engine ? plan_qtile(engine) : ppg::attn_query_tile(128);
     int rc = build_plan(chunk, overlap, maxpos, batch, frames, lengths, legacy_mode, qt, &plan);
     if (rc) return rc;
     if (engine) finish_plan(engine, &plan);
@@ -1214,7 +1222,7 @@ int ppg_plan_attention_items(const PpgEngine* engine, int batch, int frames, con
     const int overlap = engine ? engine->cfg.chunk_overlap : 50;
     const int maxpos = engine ? engine->cfg.max_positions : 5000;
     const int head_dim = engine ? engine->head_dim : 128;
-    const int qt = ppg::attn_query_tile(head_dim);
+    const int qt = engine ? plan_qtile(engine) : ppg::attn_query_tile(head_dim);
     if (engine) heads = engine->cfg.heads;
     if (heads <= 0) return fail(PPG_EINVAL, "heads=%d", heads);
     int rc = build_plan(chunk, overlap, maxpos, batch, frames, lengths, legacy_mode, qt, &plan);
@@ -1372,7 +1380,8 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32; a.heads = c.heads;
             a.dbg = l == 0 ? e->attn_dbg : nullptr;
-            LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
+            if (e->attn64) LAUNCH_OK(ppg::launch_attn64(prec, a, (int)grp.items.size(), c.heads, s), "attention");
+            else LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
         if (use32) {
             Timed t(e, PPG_K_FFN, s);

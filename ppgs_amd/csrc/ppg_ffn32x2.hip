@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int t = 0; t < XTB; ++t) {
             const int m = min(m0 + 32 * t + tok, a.M - 1);
-            float sum = 0.f, sq = 0.f;
+            f32x2 sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -130,15 +130,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const float4 bv = quad(0, rb, q);
                     yacc[rb][t][4 * q + 0] += bv.x + rv.x; yacc[rb][t][4 * q + 1] += bv.y + rv.y;
                     yacc[rb][t][4 * q + 2] += bv.z + rv.z; yacc[rb][t][4 * q + 3] += bv.w + rv.w;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = yacc[rb][t][4 * q + r];
-                        sum += v;
-                        sq = fmaf(v, v, sq);
-                    }
+                    stat4(sum2, sq2, yacc[rb][t][4 * q + 0], yacc[rb][t][4 * q + 1], yacc[rb][t][4 * q + 2], yacc[rb][t][4 * q + 3]);
                 }
-            sum = pair_sum(sum);
-            sq = pair_sum(sq);
+            const float sum = pair_sum(hsum2(sum2));
+            const float sq = pair_sum(hsum2(sq2));
             if (hh == 0) {
                 stats[wave * XTOK + 32 * t + tok] = sum;
                 stats[4 * XTOK + wave * XTOK + 32 * t + tok] = sq;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- 1. gather: thread r < TOKS + 2 HALO takes row r = token m0 - HALO + r, all channels (for one channel,
     // neighbouring threads read neighbouring frames)
-    if (tid < TOKS + 2 * HALO && !(a.debug_mode & 4)) {
+    if (tid < TOKS + 2 * HALO && !(PPG_DBG(a) & 4)) {
         const int m = m0 - HALO + tid;
         int frame = -1;
         size_t base = 0;
@@ -199,11 +199,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         });
     };
-    if (!(a.debug_mode & 1)) round(std::integral_constant<int, 0>{}, [] {});
+    if (!(PPG_DBG(a) & 1)) round(std::integral_constant<int, 0>{}, [] {});
     else __syncthreads();
     pstamp(3);
     // (the PE rows of the first row block are requested behind the round's weight wait and land under its MFMAs)
-    if (!(a.debug_mode & 1)) round(std::integral_constant<int, 1>{}, [&] { load_pe(0); });
+    if (!(PPG_DBG(a) & 1)) round(std::integral_constant<int, 1>{}, [&] { load_pe(0); });
     else load_pe(0);
 
     pstamp(4);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Layer32Args la{};
     la.wq_img = a.wq_img; la.qk_out = a.qk_out; la.vt_out = a.vt_out; la.vt_ld = a.vt_ld;
     la.blk_win = a.blk_win; la.win = a.win; la.M = a.M; la.H = HID;
-    if (!(a.debug_mode & 2)) qkv_tail<P, HID, TBS>(la, smem, m0, w1f, w2f, nblk);
+    if (!(PPG_DBG(a) & 2)) qkv_tail<P, HID, TBS>(la, smem, m0, w1f, w2f, nblk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pstamp(7);
 }

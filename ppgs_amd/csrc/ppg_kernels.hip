@@ -1666,6 +1666,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 #else
     auto stamp = [&](int, int) {};
 #endif
+#ifdef PPG_ATTN_TIMING
+    const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();   // prologue done (Q, first tiles, first scores)
+#endif
     // iteration kt: DMA K(kt+2), V(kt+1) | scores(kt+1) with softmax(kt) in its MFMA gaps | O += V P(kt)
     for (int kt = 0; kt < ntiles; ++kt) {
         stamp(kt, 0);
@@ -1717,6 +1720,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             for (int t = 0; t < NTQ; ++t) scur[kb][t] = snext[kb][t];
     }
 
+#ifdef PPG_ATTN_TIMING
+    const unsigned long long wg_t2 = __builtin_amdgcn_s_memrealtime();   // tile loop done
+#endif
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) {
         if ((qw0 + 16 * t) >= ((w.frames + 15) & ~15)) continue;
@@ -1737,7 +1743,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     if (a.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* rec = a.dbg + 64 + 4 * (size_t)blockIdx.x;
-        rec[0] = wg_t0; rec[1] = __builtin_amdgcn_s_memrealtime(); rec[2] = (unsigned long long)w.valid;
+        rec[0] = wg_t0; rec[1] = __builtin_amdgcn_s_memrealtime(); rec[2] = (unsigned long long)w.valid | ((wg_t1 - wg_t0) << 16) | ((wg_t2 - wg_t0) << 40);   // (10 ns ticks)
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         rec[3] = hwid;

@@ -19,6 +19,10 @@ hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArg
 constexpr int kFfnMixedTiling = 5;
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
+// attention at head dimension 128, 16-bit precisions, as 256-query workgroups of one wave per SIMD (ppg_attn64.hip);
+// items are (window, q0) with q0 a multiple of attn64_query_tile()
+int attn64_query_tile();
+hipError_t launch_attn64(int precision, const AttnArgs& a, int nitems, int heads, hipStream_t s);
 // feature-split layer kernel (ppg_layer32.hip): 16-bit precisions, hidden 256, F a multiple of 128
 hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s);
 // gather + input convolution + layer 0's Q/K/V of a 160-token tile (ppg_head32.hip): 16-bit precisions, hidden 256, <= 96 input channels

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __syncthreads();                             // panel and parameters are in LDS
                 pstamp(1);
             }
-            if (!(a.debug_mode & 1)) {
+            if (!(PPG_DBG(a) & 1)) {
                 stream<OffPanel<KS, 16 * kh, 0, TB>, 16 * TB, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int ks = i / TB, tb = i % TB;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
-            float sum = 0.f, sq = 0.f;
+            f32x2 sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -230,16 +230,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if constexpr (KEEP) bv = bias4[rb][q]; else bv = quad(0, rb, q);
                         yacc[rb][t][4 * q + 0] += bv.x + r8[4 * e + 0]; yacc[rb][t][4 * q + 1] += bv.y + r8[4 * e + 1];
                         yacc[rb][t][4 * q + 2] += bv.z + r8[4 * e + 2]; yacc[rb][t][4 * q + 3] += bv.w + r8[4 * e + 3];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = yacc[rb][t][4 * q + r];
-                            sum += v;
-                            sq = fmaf(v, v, sq);
-                        }
+                        stat4(sum2, sq2, yacc[rb][t][4 * q + 0], yacc[rb][t][4 * q + 1], yacc[rb][t][4 * q + 2], yacc[rb][t][4 * q + 3]);
                     }
                 }
-            sum = pair_sum(sum);
-            sq = pair_sum(sq);
+            const float sum = pair_sum(hsum2(sum2));
+            const float sq = pair_sum(hsum2(sq2));
             if (hh == 0) {
                 stats[wave * TOKS + 32 * t + tok] = sum;
                 stats[4 * TOKS + wave * TOKS + 32 * t + tok] = sq;
@@ -344,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // The two W2 sets live in the ACCUMULATION registers (loads write
         // either file, an MFMA reads its A operand from either): four sets in the 256 architectural registers made the
         // compiler park one in the other file, with copies right behind the asm loads -- of data not yet there (NaNs).
-        const int nrun = (a.debug_mode & 2) ? 0 : NCH;
+        const int nrun = (PPG_DBG(a) & 2) ? 0 : NCH;
         if (nrun > 0) {
             // chunk 0's phase A (its W1 fragments were requested above into set 0); W1 of chunk 1, then W2 of chunk 0
             bias_read(braw, 0);
@@ -438,7 +433,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         u32x4 braw[4];
         bias_read(braw, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
+        for (int c = 0; c < ((PPG_DBG(a) & 2) ? 0 : NCH); ++c) {
 #ifdef PPG_FFN_TIMING
             auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
 #else
@@ -501,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             cstamp(5);
         }
     } else {
-        for (int c = 0; c < ((a.debug_mode & 2) ? 0 : NCH); ++c) {
+        for (int c = 0; c < ((PPG_DBG(a) & 2) ? 0 : NCH); ++c) {
 #ifdef PPG_FFN_TIMING
             auto cstamp = [&](int k) { if (c == 4 && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime(); };
 #else

@@ -181,6 +181,14 @@ SYMBOLS = {
 }
 
 
+def library_sha16(path=None):
+    """First 16 hex digits of the sha256 of the built library (a clean `make` reproduces it byte for byte): what binds a
+    committed rocprofv3 counter summary (profiles/r*_pmc_summary*.txt, header `# lib_sha256_16=`) to a build."""
+    import hashlib
+    with open(path or _LIB_PATH, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def library():
     """Load libppgs_amd.so (built in-tree by __graft_entry__.build / make)."""
     global _lib

@@ -18,6 +18,8 @@ def library_sha16(path=None):
 
 if __name__ == '__main__':
     print(f'# lib_sha256_16={library_sha16()}')
+    # the arithmetic mode the counted command ran in (bench.py quotes a summary only for a step of the same mode)
+    print(f'# precision={os.environ.get("PMC_PRECISION", "bf16")}')
     for path in sys.argv[1:]:
         sums = collections.defaultdict(lambda: collections.defaultdict(float))
         counts = collections.defaultdict(lambda: collections.defaultdict(int))

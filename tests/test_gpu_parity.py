@@ -294,6 +294,28 @@ def test_c1_entry_point(golden, tmp_path):
         ppgs_amd.core.PRECISION = old
 
 
+def test_gpu_none_returns_host_tensors_like_the_reference(golden):
+    """BASELINE configs[0]'s literal call: ppgs.from_audio(audio_cpu, 16000) with gpu=None.  The reference computes on the
+    CPU there and returns a CPU tensor (ppgs/core.py:22-69, :106); this engine computes on the current HIP device, and
+    hands a caller who passed host tensors a host tensor back (`.numpy()` on the result works as it does on the
+    reference's).  A tensor already on the device, or an explicit gpu=, keeps the result on the device."""
+    g = golden('g7_c1_entry')
+    old = ppgs_amd.core.PRECISION
+    ppgs_amd.core.PRECISION = 'fp32'
+    try:
+        state = W.seeded_state_dict(seed=1234)
+        ppg = ppgs_amd.from_audio(t(g['audio']), 16000, checkpoint=state)
+        assert not ppg.is_cuda and ppg.shape == (1, 40, 100) and ppg.dtype == torch.float32
+        assert np.abs(ppg.numpy() - g['ppg']).max() < FP32_TOL
+        ppg = ppgs_amd.from_features(t(g['mel16']), torch.tensor([100]), checkpoint=state)
+        assert not ppg.is_cuda
+        assert np.abs(ppg.numpy() - g['ppg']).max() < FP32_TOL
+        assert ppgs_amd.from_audio(t(g['audio']).cuda(), 16000, checkpoint=state).is_cuda
+        assert ppgs_amd.from_audio(t(g['audio']), 16000, checkpoint=state, gpu=0).is_cuda
+    finally:
+        ppgs_amd.core.PRECISION = old
+
+
 def test_random_ragged_batches_vs_oracle():
     """Seeded ragged batches incl. zero-length items, lengths < frames,
     T just above the chunk size -- against the oracle."""
@@ -929,6 +951,32 @@ def test_c3_w2v2fb_frontend_and_engine(monkeypatch):
     oracle = O.from_features(state, feats.cpu(), frames).numpy()
     assert np.abs(ppg - oracle).max() < FP32_TOL
     w2v2fb.clear()
+
+
+@pytest.mark.parametrize('poison', ['nan', '-inf', 'inf'])
+def test_non_finite_audio_through_w2v2fb_stays_non_finite(monkeypatch, poison):
+    """the erf-form GELU of round 4 swallowed non-finite inputs (fminf / fmaxf return their non-NaN operand:
+    GELU(NaN) = GELU(-Inf) = -1e-9), and the wav2vec2 feature encoder's first GELU has no residual around it -- NaN
+    audio came out as finite garbage.  torch's gelu gives NaN for NaN, -Inf and +Inf... the feature rows the bad
+    sample reaches must be non-finite here too."""
+    monkeypatch.setenv('PPGS_AMD_W2V2_RANDOM_INIT', '7')
+    from ppgs_amd.preprocess import w2v2fb
+    w2v2fb.clear()
+    gen = torch.Generator().manual_seed(6)
+    audio = 0.1 * torch.randn(2, 1, 16000, generator=gen)
+    audio[1, 0, 8000] = float(poison)
+    old = ppgs_amd.core.PRECISION
+    try:
+        for precision in ('fp32', 'fp16', 'bf16'):
+            ppgs_amd.core.PRECISION = precision
+            feats = w2v2fb.from_audios(audio, torch.tensor([16000, 16000]), gpu=0).float()
+            assert bool(torch.isfinite(feats[0]).all()), precision
+            assert not bool(torch.isfinite(feats[1]).all()), (precision, poison)
+    finally:
+        ppgs_amd.core.PRECISION = old
+    w2v2fb.clear()
+    # the activation itself, through the body's GELU GEMM epilogue and the token-split one: covered by the above for the
+    # encoder; the device function is one: gelu_erf / gelu_erf_pair (ppg_device.h)
 
 
 def test_c3_w2v2fb_fp16x2_route(monkeypatch):

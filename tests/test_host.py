@@ -214,17 +214,21 @@ def test_no_kernel_is_exposed_to_the_packed_fp32_mfma_hazard():
     """on gfx950 a v_pk_add/mul/fma_f32 with op_sel set on SOURCE 1 computes with the wrong operand half,
     intermittently, while another wave of its SIMD issues 16x16x32 MFMAs (tools/probes/pk_mfma_probe.hip; it is what
     made round 2's mel frontend wrong beside attention kernels).  hipcc writes that form by itself, so the BUILT
-    library's ISA is audited: no kernel whose waves can share a SIMD (<= 256 registers per lane) may contain it."""
+    library's ISA is audited: NO kernel may contain it, whatever its register allocation (a > 256-register kernel keeps
+    its own waves apart, but another kernel's small MFMA wave fits in the 512 - vgprs registers it leaves)."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
         pytest.skip('no llvm-objdump')
+    if not os.path.exists(os.path.join(root, 'ppgs_amd', 'libppgs_amd.so')):
+        pytest.skip('library not built')
     run = subprocess.run([sys.executable, os.path.join(root, 'tools', 'pk_scan.py'), '--strict'],
                          capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-4000:] + run.stderr[-2000:]
     assert ' 0 exposed' in run.stdout
     # the audit sees the kernels that matter and knows the vulnerable form when it meets it
-    assert 'frontend_kernel' in run.stdout and 'attn_mixed_kernel' in run.stdout and 'one wave per SIMD' in run.stdout
+    assert 'frontend_kernel' in run.stdout and 'attn_mixed_kernel' in run.stdout and 'layer32_kernel' in run.stdout
+    assert 'one wave per SIMD' not in run.stdout          # (round 4's exemption class is gone)
     sys.path.insert(0, os.path.join(root, 'tools'))
     import pk_scan
     assert pk_scan.vulnerable('v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]')
@@ -344,7 +348,7 @@ def test_hot_kernels_do_not_wait_for_store_acknowledgements():
     kernels = wait_scan.scan(library)
     budget = {
         'layer32_kernel<PrecBF16, 256, true, 5>': 4, 'layer32_kernel<PrecBF16, 256, false, 5>': 0,
-        'head32_kernel<PrecBF16, 5>': 12, 'attn_mixed_kernel<PrecBF16>': 2, 'outconv_kernel<PrecBF16>': 0,
+        'head32_kernel<PrecBF16, 5>': 13, 'attn_mixed_kernel<PrecBF16>': 2, 'outconv_kernel<PrecBF16>': 0,
         'gemm32_kernel<PrecBF16, 4, 0>': 0, 'gemm32_kernel<PrecBF16, 4, 1>': 0, 'gemm32_kernel<PrecBF16, 5, 3>': 0,
         'posconv_kernel<PrecBF16>': 0, 'w2v2_layernorm_kernel<PrecBF16, 768>': 0,
         'linear_kernel<PrecBF16, 1, 16, 1>': 1, 'ffn32x2_kernel<true, true>': 3,

@@ -17,7 +17,7 @@ find gpurun_out/prof_$tag/trace -name "*kernel_stats.csv" | head -1 | xargs -I{}
 ( cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_x2/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision fp16x2 --no-cpu --no-alt --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/prof_x2.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_x2/pmc1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision fp16x2 --no-cpu --no-alt --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/$out/prof_x2_pmc.log 2>&1 )
-python tests/pmc_summary.py gpurun_out/prof_${tag}_x2/pmc1/bench_counter_collection.csv > $out/${tag}_pmc_summary_fp16x2.txt 2>>$out/pmc_summary.err
+PMC_PRECISION=fp16x2 python tests/pmc_summary.py gpurun_out/prof_${tag}_x2/pmc1/bench_counter_collection.csv > $out/${tag}_pmc_summary_fp16x2.txt 2>>$out/pmc_summary.err
 find gpurun_out/prof_${tag}_x2/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats_fp16x2.csv
 round=$(echo $tag | sed 's/^\(r[0-9]*\).*/\1/')
 cp $out/${tag}_pmc_summary.txt profiles/${round}_pmc_summary.txt
