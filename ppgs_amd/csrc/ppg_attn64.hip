@@ -16,10 +16,10 @@
 // add up.  Here a wave has the SIMD to itself and TWICE the queries: every K / V^T fragment read from LDS feeds two
 // 32-query blocks... of which there are two per wave, A and B, whose phases interleave --
 //
-//     MFMA   | S_A(t)      | P V_B(t-1)   | S_B(t)       | P V_A(t)      |   S = K q^T - shift,  16 MFMAs of 32 cycles each
-//     VALU   | exp_B(t-1) 2nd half | exp_A(t) 1st | exp_A(t) 2nd | exp_B(t) 1st |
+//     MFMA   | S_A(t) x P V_A(t-1), alternating | S_B(t) x P V_B(t-1), alternating |      S = K q^T - shift, MFMAs of 32 cycles
+//     VALU   | exp_B(t-1)                        | exp_A(t)                          |
 //
-// so the softmax of one block always runs in the gaps of the other block's MFMAs, two phases ahead of the product that
+// so the softmax of one block always runs in the gaps of the other block's MFMAs, a phase ahead of the product that
 // needs it: 3 VALU slots per 32-cycle MFMA (two v_exp_f32, or a packed add and a convert).  The 64 MFMAs of a tile are
 // ONE stream of LDS fragment reads, 8 in flight, that runs on across the phases and across the tile loop's back edge.
 // K and V^T tiles of 64 keys arrive by global -> LDS DMA three tiles ahead into rings of 3 / 4 slots (112 KiB: the
@@ -68,10 +68,13 @@ __device__ __forceinline__ void a64_read(u32x4& dst, uint32_t addr) {
 // its last writer (the first exponentials of a block read key block 0, written by the phase's second-to-last MFMA),
 // and the places where compiler code reads accumulators right behind the stream (first tile, masks, epilogue) carry
 // their own s_nop runs.
+// (s_first: the C operand may have been written by the instruction in front -- the compiler materialises the zero
+// tuple of the first tile with v_mov_b64 right there, and a VALU write needs two wait states before an MFMA reads it:
+// found as scores of key 0 and 1 made of whatever the registers held before, 0x5a5a5a5a on a fresh box)
 template <class P> struct A64Op;
 template <> struct A64Op<PrecBF16> {
     static __device__ __forceinline__ void s_first(f32x16& d, const u32x4& k, const u32x4& q, const f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "a"(c));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
     }
     static __device__ __forceinline__ void s_acc(f32x16& d, const u32x4& k, const u32x4& q) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
@@ -79,7 +82,7 @@ template <> struct A64Op<PrecBF16> {
 };
 template <> struct A64Op<PrecF16> {
     static __device__ __forceinline__ void s_first(f32x16& d, const u32x4& k, const u32x4& q, const f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "a"(c));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
     }
     static __device__ __forceinline__ void s_acc(f32x16& d, const u32x4& k, const u32x4& q) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
@@ -122,6 +125,17 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, const AttnItem& i
         }
     };
 
+    // ... one piece at a time (piece 0..3: K, 4..7: V^T), for the tile loop: a DMA instruction costs its wave tens of issue cycles
+    auto stage_piece = [&](int kt, auto pc) {
+        constexpr int pi = decltype(pc)::value, i = pi & 3;
+        if constexpr (pi < 4) {
+            glds16(kbase + (size_t)(kt * A64_KT + 4 * wave + 16 * i) * a.qk_ld_bytes, koff,
+                   lds0 + (uint32_t)((kt % A64_NK) * A64_TILE + wave * 1024 + i * 4096));
+        } else {
+            glds16(vbase + (size_t)(8 * wave + 32 * i) * a.vt_ld_bytes + (size_t)kt * 128, voff,
+                   lds0 + (uint32_t)(A64_LV + (kt % A64_NV) * A64_TILE + wave * 1024 + i * 4096));
+        }
+    };
     int kend = item.valid;
     if (a.causal) kend = min(kend, item.q0 + 4 * 32 * NQB);
     const int ntiles = (kend + A64_KT - 1) / A64_KT;
@@ -229,7 +243,7 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, const AttnItem& i
         shift[b] += d;
 #pragma unroll
         for (int R = 0; R < 16; ++R) cinit[b][R] = -shift[b];
-        asm volatile("" : "+a"(cinit[b]));          // (opaque: or the splat is re-made from one register in front of every use)
+        asm volatile("" : "+v"(cinit[b]));          // (opaque: or the splat is re-made from one register in front of every use)
     };
     // end of block b's softmax of a tile: the ceiling test (wave-uniform, cold branch), the running sum
     auto sm_close = [&](auto bc) {
@@ -284,7 +298,7 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, const AttnItem& i
             shift[b] = (m0 == -INFINITY) ? 0.f : m0;
 #pragma unroll
             for (int R = 0; R < 16; ++R) cinit[b][R] = -shift[b];
-            asm volatile("" : "+a"(cinit[b]));
+            asm volatile("" : "+v"(cinit[b]));
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -296,127 +310,159 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, const AttnItem& i
                    sm_pack(std::integral_constant<int, 0>{}, std::integral_constant<int, J>{}, e); }(), ...);
         }(std::make_integer_sequence<int, 16>{});
         sm_close(std::integral_constant<int, 0>{});
+        // (VALU-written P fragments -> MFMA operands: the packs may not sink to the MFMA that reads them)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) asm volatile("" : "+v"(pf[0][sidx]));
+        asm volatile("s_nop 1" ::: "memory");
     }
 #ifdef PPG_ATTN_TIMING
     const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // ---- the tile loop -----------------------------------------------------------------------------------------------
-    // Steps of iteration t (fragment read 8 steps ahead of its MFMA):
-    //    0..15  S_A(t):   K(t) fragment (ks, kb) = (i / 2, i % 2)                      fillers: exp_B(t-1) half-quads 8..15, close B
-    //   16..31  P V_B(t-1): V^T(t-1) fragment (s, db) = (j / 4, j % 4)                 fillers: [mask A] exp_A(t) half-quads 0..7, vaddr -> V^T(t)
-    //   32..47  S_B(t):   K(t) again                                                   fillers: exp_A(t) half-quads 8..15, close A, kaddr -> K(t+1)
-    //   48..63  P V_A(t): V^T(t) fragment                                              fillers: barrier, DMA of tile t + 3, [mask B] exp_B(t) half-quads 0..7
-    // Iteration 0 runs steps 48..63 only (its scores and block A's softmax are the prologue above).
-    int kdelta = 0, vdelta = 0;            // byte steps of the ring addresses into the next tile's slots
+    // Iteration t = 1 .. T-1, 64 steps, the fragment of a step read 8 steps ahead of its MFMA:
+    //    0..31  even i: S_A(t)  on K(t) fragment (ks, kb) = (n / 2, n % 2), n = i / 2        odd i: P V_A(t-1) on V^T(t-1) fragment
+    //   32..63  even i: S_B(t)                                                               odd i: P V_B(t-1)    (s, db) = (n / 4, n % 4)
+    //   gaps 0..31: [mask B(t-1)] exp_B(t-1), close B        gaps 32..63: [mask A(t)] exp_A(t), close A
+    // Score and output MFMAs ALTERNATE: an accumulator is touched by every 4th (scores) / 8th (output) MFMA of the
+    // stream.  With a phase of nothing but one block's scores -- two accumulators in turn -- every MFMA waited for the
+    // one two slots ahead of it to write its result back: 60 - 78 cycles per MFMA against 43 in the output phases
+    // (per-phase stamps of the first version, profiles/r5_attn64_phases.txt).
+    // The price is one tile more of latency in the pipeline: the product of tile t-1 runs beside the scores of tile t.
+    // Barrier at step 48 (tile t + 1 landed, issued a whole iteration ago), then the DMA of tile t + 2 into the slots of
+    // K(t - 1) and V^T(t - 2), one piece per gap.
+    int kdelta = 0, vdelta = 0;            // byte steps of the ring addresses into the next iteration's slots
     auto read_of = [&](auto jc, u32x4& dst) {      // the fragment of step j (j >= 64: of the next iteration)
-        constexpr int j = decltype(jc)::value % 64;
-        if constexpr (j < 16 || (j >= 32 && j < 48)) a64_read<(j % 2) * 8192>(dst, kaddr[(j % 16) / 2]);
-        else a64_read<((j % 16) % 4) * 4096>(dst, vaddr[(j % 16) / 4]);
+        constexpr int j = decltype(jc)::value % 64, n = (j % 32) / 2;
+        if constexpr (j % 2 == 0) a64_read<(n % 2) * 8192>(dst, kaddr[n / 2]);
+        else a64_read<(n % 4) * 4096>(dst, vaddr[n / 4]);
     };
-    // A phase of 16 steps: MFMA of step i on its fragment, the read 8 steps ahead, filler(j) in the gap
-    auto run16 = [&](auto phc, auto filler) {
-        constexpr int ph = decltype(phc)::value;
-        [&]<int... J>(std::integer_sequence<int, J...>) {
+#if defined(PPG_ATTN_TIMING) && defined(A64_STAMPS)
+    auto stamp = [&](int tt, int k) {
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && tt >= 2 && tt < 4) a.dbg[(wave * 2 + (tt - 2)) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](int, int) {};
+#endif
+    f32x2 ehold;
+    // gap g of a 32-gap phase carries half-quad g / 2 of block b: the exponentials in the even gap, sum + pack in the odd one
+    auto sm_fill = [&](auto bc, auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g % 2 == 0) sm_exp(bc, std::integral_constant<int, g / 2>{}, ehold);
+        else sm_pack(bc, std::integral_constant<int, g / 2>{}, ehold);
+    };
+    auto run32 = [&](auto halfc, auto filler) {
+        constexpr int half = decltype(halfc)::value;       // 0: block A's scores + product, 1: block B's
+        [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
-                constexpr int j = J, i = 16 * ph + J;
+                constexpr int i = 32 * half + G, n = G / 2;
                 u32x4& frag = ring[i % A64_D];
                 lgkm_wait32<A64_D - 1>(frag);
-                if constexpr (ph == 0 || ph == 2) {
-                    constexpr int b = ph / 2;
-                    if constexpr (j / 2 == 0) A64Op<P>::s_first(sacc[b][j % 2], frag, qf[b][0], cinit[b]);
-                    else A64Op<P>::s_acc(sacc[b][j % 2], frag, qf[b][j / 2]);
+                if constexpr (G % 2 == 0) {
+                    if constexpr (n / 2 == 0) A64Op<P>::s_first(sacc[half][n % 2], frag, qf[half][0], cinit[half]);
+                    else A64Op<P>::s_acc(sacc[half][n % 2], frag, qf[half][n / 2]);
                 } else {
-                    constexpr int b = ph == 1 ? 1 : 0;
-                    A64O<P, 4 * b + j % 4>::acc(frag, pf[b][j / 4]);
+                    A64O<P, 4 * half + n % 4>::acc(frag, pf[half][n / 4]);
                 }
-                if constexpr (i == 39) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) vaddr[s] += (uint32_t)vdelta;
-                }
-                if constexpr (i == 55) {
+                if constexpr (i == 56) {          // the reads from here on are the next iteration's
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) kaddr[ks] += (uint32_t)kdelta;
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) vaddr[sidx] += (uint32_t)vdelta;
                 }
+#ifndef A64_ABL_NOREAD
                 read_of(std::integral_constant<int, i + A64_D>{}, frag);
-                filler(std::integral_constant<int, J>{});
+#endif
+                __builtin_amdgcn_sched_barrier(0);      // (the gap's VALU work BEHIND the MFMA)
+                filler(std::integral_constant<int, G>{});
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
-        }(std::make_integer_sequence<int, 16>{});
+        }(std::make_integer_sequence<int, 32>{});
     };
-    // softmax fillers: gap j of a phase carries half-quad HQ0 + j / 2: the exponentials in the even gap, sum + pack in the odd one
-    f32x2 ehold;
-    auto sm_fill = [&](auto bc, auto hq0c, auto jc) {
-        constexpr int j = decltype(jc)::value, hq = decltype(hq0c)::value + j / 2;
-        if constexpr (j % 2 == 0) sm_exp(bc, std::integral_constant<int, hq>{}, ehold);
-        else sm_pack(bc, std::integral_constant<int, hq>{}, ehold);
-    };
-    auto phase_d = [&](int tt) {
-        // P V_A(tt) | barrier: tile tt + 1 visible, K(tt) and V^T(tt - 1) free | DMA of tile tt + 3 | exp_B(tt) half-quads 0..7
-        const bool maskb = need_mask(1, tt);
-        run16(std::integral_constant<int, 3>{}, [&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (j == 0) {
-                if (tt + 2 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_barrier" ::: "memory");
-                if (maskb) mask_block(1, tt);
-            }
-            if constexpr (j == 1) { if (tt + 3 < ntiles) stage(tt + 3); }
-            sm_fill(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, jc);
-        });
-    };
-    if (ntiles > 0) {
-        // prime the ring with V^T(0)'s first fragments (steps 48..55), then iteration 0's phase D
-        kdelta = A64_TILE;                                      // K(0) -> K(1) at step 55
-        [&]<int... I>(std::integer_sequence<int, I...>) { (read_of(std::integral_constant<int, 48 + I>{}, ring[(48 + I) % A64_D]), ...); }(std::make_integer_sequence<int, A64_D>{});
-        phase_d(0);
+    if (ntiles > 1) {
+        // tile 1 landed for every wave; the ring starts on K(1) / V^T(0)
+        if (ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kaddr[ks] += A64_TILE;
+        [&]<int... I>(std::integer_sequence<int, I...>) { (read_of(std::integral_constant<int, I>{}, ring[I]), ...); }(std::make_integer_sequence<int, A64_D>{});
     }
     for (int tt = 1; tt < ntiles; ++tt) {
-        vdelta = (tt % A64_NV == 0) ? -(A64_NV - 1) * A64_TILE : A64_TILE;             // V^T(tt-1) -> V^T(tt) at step 39
-        kdelta = ((tt + 1) % A64_NK == 0) ? -(A64_NK - 1) * A64_TILE : A64_TILE;       // K(tt) -> K(tt+1) at step 55
-        const bool maska = need_mask(0, tt);
-        // S_A(tt) | exp_B(tt-1) half-quads 8..15, close B
-        run16(std::integral_constant<int, 0>{}, [&](auto jc) {
-            sm_fill(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{}, jc);
-            if constexpr (decltype(jc)::value == 15) sm_close(std::integral_constant<int, 1>{});
+        kdelta = ((tt + 1) % A64_NK == 0) ? -(A64_NK - 1) * A64_TILE : A64_TILE;       // K(tt) -> K(tt + 1)
+        vdelta = (tt % A64_NV == 0) ? -(A64_NV - 1) * A64_TILE : A64_TILE;             // V^T(tt - 1) -> V^T(tt)
+        const bool maskb = need_mask(1, tt - 1), maska = need_mask(0, tt);
+        stamp(tt, 0);
+        run32(std::integral_constant<int, 0>{}, [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g == 0) { if (maskb) mask_block(1, tt - 1); }
+#ifndef A64_ABL_NOSOFTMAX
+            sm_fill(std::integral_constant<int, 1>{}, gc);
+#endif
+            if constexpr (g == 15) stamp(tt, 1);
+            if constexpr (g == 31) sm_close(std::integral_constant<int, 1>{});
         });
-        // P V_B(tt-1) | [mask A] exp_A(tt) half-quads 0..7
-        run16(std::integral_constant<int, 1>{}, [&](auto jc) {
-            if constexpr (decltype(jc)::value == 0) { if (maska) mask_block(0, tt); }
-            sm_fill(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, jc);
+        stamp(tt, 2);
+        run32(std::integral_constant<int, 1>{}, [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g == 0) { if (maska) mask_block(0, tt); }
+            if constexpr (g == 16) {
+                stamp(tt, 3);
+#ifndef A64_ABL_NOBARRIER
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+#endif
+                stamp(tt, 4);
+            }
+#ifndef A64_ABL_NODMA
+            if constexpr (g >= 17 && g <= 24) { if (tt + 2 < ntiles) stage_piece(tt + 2, std::integral_constant<int, g - 17>{}); }
+#endif
+#ifndef A64_ABL_NOSOFTMAX
+            sm_fill(std::integral_constant<int, 0>{}, gc);
+#endif
+            if constexpr (g == 31) sm_close(std::integral_constant<int, 0>{});
         });
-        // S_B(tt) | exp_A(tt) half-quads 8..15, close A
-        run16(std::integral_constant<int, 2>{}, [&](auto jc) {
-            sm_fill(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, jc);
-            if constexpr (decltype(jc)::value == 15) sm_close(std::integral_constant<int, 0>{});
-        });
-        phase_d(tt);
+        stamp(tt, 5);
     }
-    // the reads primed for a next iteration that does not exist
+    // the reads primed for an iteration that does not exist
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < A64_D; ++i) asm volatile("" : "+v"(ring[i]));
     if (ntiles > 0) {
-        // block B's last softmax half and product: exp_B(T-1) half-quads 8..15, close B, P V_B(T-1) on V^T(T-1) (vaddr is there)
-        [&]<int... J>(std::integer_sequence<int, J...>) {
-            ([&] { f32x2 e; sm_exp(std::integral_constant<int, 1>{}, std::integral_constant<int, 8 + J>{}, e);
-                   sm_pack(std::integral_constant<int, 1>{}, std::integral_constant<int, 8 + J>{}, e); }(), ...);
-        }(std::make_integer_sequence<int, 8>{});
-        sm_close(std::integral_constant<int, 1>{});
+        // the last tile's products: P V_A(T-1) with exp_B(T-1) in its gaps (a half-quad per gap), then P V_B(T-1);
+        // vaddr points at V^T(T-1) (the last iteration moved it there; with one tile it never moved)
+        if (ntiles > 1) {
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) asm volatile("" : "+v"(vaddr[sidx]));
+        }
+        const bool maskb = need_mask(1, ntiles - 1);
+        if (maskb) mask_block(1, ntiles - 1);
         auto rdv = [&](auto ic, u32x4& dst) {
-            constexpr int i = decltype(ic)::value;
+            constexpr int i = decltype(ic)::value % 16;
             a64_read<(i % 4) * 4096>(dst, vaddr[i / 4]);
         };
         [&]<int... I>(std::integer_sequence<int, I...>) { (rdv(std::integral_constant<int, I>{}, ring[I]), ...); }(std::make_integer_sequence<int, A64_D>{});
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
-                lgkm_wait32<(15 - I < A64_D - 1) ? (15 - I) : (A64_D - 1)>(ring[I % A64_D]);
-                A64O<P, 4 + I % 4>::acc(ring[I % A64_D], pf[1][I / 4]);
-                if constexpr (I + A64_D < 16) rdv(std::integral_constant<int, I + A64_D>{}, ring[I % A64_D]);
+                lgkm_wait32<(31 - I < A64_D - 1) ? (31 - I) : (A64_D - 1)>(ring[I % A64_D]);
+                if constexpr (I < 16) A64O<P, I % 4>::acc(ring[I % A64_D], pf[0][I / 4]);
+                else A64O<P, 4 + I % 4>::acc(ring[I % A64_D], pf[1][(I - 16) / 4]);
+                if constexpr (I + A64_D < 32) rdv(std::integral_constant<int, I + A64_D>{}, ring[I % A64_D]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (I < 16) {
+                    f32x2 e;
+                    sm_exp(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{}, e);
+                    sm_pack(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{}, e);
+                    if constexpr (I == 15) {
+                        sm_close(std::integral_constant<int, 1>{});
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx) asm volatile("" : "+v"(pf[1][sidx]));
+                        asm volatile("s_nop 1" ::: "memory");
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
-        }(std::make_integer_sequence<int, 16>{});
+        }(std::make_integer_sequence<int, 32>{});
     }
     a64_mfma_settle();
 #ifdef PPG_ATTN_TIMING

@@ -276,7 +276,7 @@ struct PpgEngine {
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
-    bool attn64 = false;     // whole-batch attention on ppg_attn64.hip (head dimension 128, 16-bit modes; PPGS_AMD_ATTN64=0: attn_mixed_kernel)
+    bool attn64 = false;     // PPGS_AMD_ATTN64=1: whole-batch attention on ppg_attn64.hip (head dimension 128, 16-bit modes) instead of attn_mixed_kernel
     unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
     int ffn32x2 = 3;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 3 = out-proj + LN1 + FFN + LN2 + the next layer's Q/K/V in ONE feature-split launch per layer (ppg_ffn32x2.hip), 2 = without the Q/K/V tail, 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
     bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
@@ -958,8 +958,11 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
-    e->attn64 = e->head_dim == 128 && (cfg->precision == PPG_PRECISION_BF16 || cfg->precision == PPG_PRECISION_FP16);
-    if (const char* v = getenv("PPGS_AMD_ATTN64")) e->attn64 = e->attn64 && atoi(v) != 0;
+    // (ppg_attn64.hip: built and parity-green, NOT the default -- at 32 x 1000 frames its long workgroups take 25 us
+    // against 21 and the 64 short ones a second round of 14 us on a quarter of the chip: DESIGN 4.2, profiles/r5_attn64_*)
+    e->attn64 = false;
+    if (const char* v = getenv("PPGS_AMD_ATTN64"))
+        e->attn64 = atoi(v) != 0 && e->head_dim == 128 && (cfg->precision == PPG_PRECISION_BF16 || cfg->precision == PPG_PRECISION_FP16);
     if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_SUBTILE")) e->subtile = atoi(v) != 0;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), 256));
