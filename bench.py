@@ -146,6 +146,35 @@ class ClockSampler:
                 'median_mhz': ordered[len(ordered) // 2], 'samples': len(ordered), 'source': self.path}
 
 
+def dense_mfma_probe():
+    """tools/bin/mfma_clock_probe (stand-alone HIP program, built by tools/probes/build.sh): v_mfma_f32_32x32x16_bf16 back
+    to back on every SIMD of the chip -- the clock the chip DELIVERS with all matrix pipes busy (s_memtime cycles per
+    s_memrealtime microsecond) and the FLOP/s that is.  The 2.5 PFLOP/s every `frac` here divides by is quoted at
+    2.4 GHz; under its power limit the chip runs such a loop at ~1.9 GHz.  Reported beside the line, never used in it.
+    -> dict or None (binary absent / failed)."""
+    import re
+    import subprocess
+    path = os.path.join(ROOT, 'tools', 'bin', 'mfma_clock_probe')
+    if not os.path.exists(path):
+        return None
+    try:
+        text = subprocess.run([path, '400'], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    rows = {}
+    for line in text.splitlines():
+        m = re.match(r'(.+?)\s+grid\s+(\d+)\s+([0-9.]+) us\s+clock GHz p10/50/90 ([0-9.]+) ([0-9.]+) ([0-9.]+)\s+cycles per MFMA p50 ([0-9.]+)\s+([0-9.]+) TFLOP/s', line)
+        if m:
+            rows[m.group(1).strip()] = {'clock_ghz_p50': float(m.group(5)), 'cycles_per_mfma': float(m.group(7)), 'tflops': float(m.group(8))}
+    dense = rows.get('MFMA only, 1 wave per SIMD, 10x longer') or rows.get('MFMA only, 1 wave per SIMD')
+    if not dense:
+        return None
+    return {'what': 'stand-alone dense v_mfma_f32_32x32x16_bf16 loop on every SIMD (tools/probes/mfma_clock_probe.hip), run after the '
+                    'timed region: what the chip delivers under its power limit with all matrix pipes busy',
+            'dense': dense, 'with_3_valu_per_mfma': rows.get('MFMA + 3 VALU, 1 wave per SIMD'),
+            'with_6_valu_per_mfma': rows.get('MFMA + 6 VALU, 1 wave per SIMD'), 'half_the_cus': rows.get('MFMA only, half the CUs')}
+
+
 def parse(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
@@ -623,6 +652,14 @@ def run_c2(args, rank, world, local_rank, use_dist):
         line['alt_single_pipeline'] = alt_streams
     if alt_graph:
         line['alt_graph_replay'] = alt_graph
+    if rank == 0 and world == 1:
+        probe = dense_mfma_probe()
+        line['dense_mfma_probe'] = probe
+        if probe and args.precision != 'fp32':
+            # the same fractions against what the probe measured on THIS box instead of the nominal 2.5 PFLOP/s
+            delivered = probe['dense']['tflops']
+            line['roofline']['frac_of_delivered_dense_peak'] = ffn_tflops / delivered
+            line['end_to_end_frac_of_delivered_dense_peak'] = line['end_to_end_tflops'] / delivered
     if world == 1 and not args.no_cpu:
         line['cpu_baseline'] = cpu_baseline(state, args.cpu_seconds)
         line['speedup_vs_cpu'] = frames_per_s / line['cpu_baseline']['value']

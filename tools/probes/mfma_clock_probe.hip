@@ -50,17 +50,17 @@ __global__ __launch_bounds__(256) void dense_mfma(int iters, unsigned long long*
 template <int VALU>
 void run(const char* name, int grid, int iters, unsigned long long* d_rec, float* d_sink) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {          // (the first launches run on a chip that was idle)
-        hipEventRecord(e0, 0);
+        (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(dense_mfma<VALU>, dim3(grid), dim3(256), 0, 0, iters, d_rec, d_sink);
-        hipEventRecord(e1, 0);
-        hipEventSynchronize(e1);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
     }
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> rec(2 * grid * 4);
-    hipMemcpy(rec.data(), d_rec, rec.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(rec.data(), d_rec, rec.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> ghz, cyc;
     for (int i = 0; i < grid * 4; ++i) {
         ghz.push_back((double)rec[2 * i] / ((double)rec[2 * i + 1] * 10.0));          // cycles per ns
@@ -76,11 +76,11 @@ void run(const char* name, int grid, int iters, unsigned long long* d_rec, float
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 400;
     hipDeviceProp_t prop;
-    hipGetDeviceProperties(&prop, 0);
+    (void)hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     printf("%s: %d CUs, iters %d (x 64 MFMAs of 32x32x16 bf16 per wave)\n", prop.name, cus, iters);
     unsigned long long* d_rec; float* d_sink;
-    hipMalloc(&d_rec, 2 * 8 * 4 * 2 * cus * 8); hipMalloc(&d_sink, 64);
+    (void)hipMalloc(&d_rec, 2 * 8 * 4 * 2 * cus * 8); (void)hipMalloc(&d_sink, 64);
     run<0>("MFMA only, 1 wave per SIMD", cus, iters, d_rec, d_sink);
     run<0>("MFMA only, 2 waves per SIMD", 2 * cus, iters, d_rec, d_sink);
     run<3>("MFMA + 3 VALU, 1 wave per SIMD", cus, iters, d_rec, d_sink);
