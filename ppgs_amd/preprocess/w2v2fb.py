@@ -3,13 +3,15 @@ ppgs/preprocess/w2v2fb/core.py:32-75.
 
 The reference delegates the body to the third-party HF ``Wav2Vec2Model``
 ('facebook/wav2vec2-base').  Here the whole model runs in the hand-written HIP
-engine: the convolutional feature encoder (7 strided convolutions, GroupNorm,
-GELU; ``engine.W2v2FeatureEncoder``, ppg_w2v2.hip + linear_kernel<EPI_GELU>)
-and the feature projection + 12-layer transformer (``engine.W2v2Body``:
-linear_kernel<EPI_GENERAL>, attention at head dimension 64, row LayerNorms,
-the grouped positional convolution as 16 GEMMs of one launch) -- SURVEY.md
-8(f) rank 1.  Everything after the latents -- the 768-channel, hidden-512 PPG
-network -- runs in the HIP engine too.  PPGS_AMD_W2V2_BODY=0 keeps the HF
+engine: the convolutional feature encoder (``engine.W2v2FeatureEncoder``:
+layer 0 with its GroupNorm statistics from 65 moments of the audio in
+ppg_w2v2.hip, layers 1-6 as strided-row MFMA GEMMs with an exact-GELU epilogue)
+and the feature projection + 12-layer transformer (``engine.W2v2Body``: every
+projection on the feature-split ``gemm32_kernel`` of ppg_gemm32.hip, the
+grouped positional convolution as its own kernel ppg_posconv.hip, attention at
+head dimension 64, LayerNorm-768 row kernels) -- SURVEY.md 8(f) rank 1,
+DESIGN.md 4.5.  Everything after the latents -- the 768-channel, hidden-512
+PPG network -- runs in the HIP engine too.  PPGS_AMD_W2V2_BODY=0 keeps the HF
 projection / encoder modules on PyTorch-ROCm, PPGS_AMD_W2V2_NATIVE=0 runs the
 whole HF model there.
 
