@@ -161,6 +161,11 @@ def dense_mfma_probe():
         text = subprocess.run([path, '400'], capture_output=True, text=True, timeout=60).stdout
     except (OSError, subprocess.TimeoutExpired):
         return None
+    return parse_mfma_probe(text)
+
+
+def parse_mfma_probe(text):
+    import re
     rows = {}
     for line in text.splitlines():
         m = re.match(r'(.+?)\s+grid\s+(\d+)\s+([0-9.]+) us\s+clock GHz p10/50/90 ([0-9.]+) ([0-9.]+) ([0-9.]+)\s+cycles per MFMA p50 ([0-9.]+)\s+([0-9.]+) TFLOP/s', line)

@@ -356,3 +356,39 @@ def test_hot_kernels_do_not_wait_for_store_acknowledgements():
     for name, allowed in budget.items():
         assert name in kernels, name
         assert kernels[name]['vmcnt0_after_store'] <= allowed, (name, dict(kernels[name]))
+
+
+def test_bench_refuses_experiment_switches_and_reads_the_clock_probe(monkeypatch, tmp_path):
+    """bench.py's line is self-defending: with a PPGS_AMD_* experiment switch in the environment it
+    exits before touching the GPU (--allow-ablation: the switches are carried in the line, its `value` nulled);
+    configuration switches (PPGS_AMD_STREAMS ...) are recorded, not refused.  And the two text parsers beside the line:
+    the driver's sysfs clock file and the stand-alone dense-MFMA probe's output."""
+    import argparse
+    import importlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    for key in list(os.environ):
+        if key.startswith('PPGS_AMD_'):
+            monkeypatch.delenv(key)
+    args = argparse.Namespace(allow_ablation=False)
+    monkeypatch.setenv('PPGS_AMD_STREAMS', '1')
+    assert bench.env_guard(args) == ({'PPGS_AMD_STREAMS': '1'}, {})
+    monkeypatch.setenv('PPGS_AMD_LAYER32', '0')
+    with pytest.raises(SystemExit):
+        bench.env_guard(args)
+    args.allow_ablation = True
+    assert bench.env_guard(args)[1] == {'PPGS_AMD_LAYER32': '0'}
+    # sysfs: the line with the star is the current level
+    clock = tmp_path / 'pp_dpm_sclk'
+    clock.write_text('0: 500Mhz \n1: 1873Mhz *\n2: 2400Mhz \n')
+    sampler = bench.ClockSampler.__new__(bench.ClockSampler)
+    sampler.path = str(clock)
+    assert sampler._read() == 1873.0
+    # the probe record committed with round 5
+    with open(os.path.join(root, 'profiles', 'r5_mfma_clock_probe.txt')) as f:
+        probe = bench.parse_mfma_probe(f.read())
+    assert 1.5 < probe['dense']['clock_ghz_p50'] < 2.4 and 31.5 < probe['dense']['cycles_per_mfma'] < 33.0
+    assert 0.6 < probe['dense']['tflops'] / 2500.0 < 0.9
+    assert probe['with_6_valu_per_mfma']['tflops'] < probe['with_3_valu_per_mfma']['tflops'] < probe['dense']['tflops']
