@@ -1980,7 +1980,7 @@ struct PpgW2v2 {
 
 int ppg_w2v2_create(const PpgW2v2Weights* wts, int precision, int device, PpgW2v2** out) {
     if (!wts || !out) return fail(PPG_EINVAL, "null argument");
-    if (precision != PPG_PRECISION_FP32 && precision != PPG_PRECISION_BF16 && precision != PPG_PRECISION_FP16)
+    if (precision != PPG_PRECISION_FP32 && precision != PPG_PRECISION_BF16 && precision != PPG_PRECISION_FP16 && precision != PPG_PRECISION_FP16X2)
         return fail(PPG_EINVAL, "precision %d", precision);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1991,7 +1991,9 @@ int ppg_w2v2_create(const PpgW2v2Weights* wts, int precision, int device, PpgW2v
     PpgEngine* E = &m->eng;
     E->device = device;
     E->cfg.precision = precision;
-    E->sz = precision == PPG_PRECISION_FP32 ? 4 : 2;
+    // (fp16x2: layers 1..6 with every operand an fp16 hi + lo pair in the fp32 path's byte layout -- PrecX2)
+    E->split = precision == PPG_PRECISION_FP16X2;
+    E->sz = (precision == PPG_PRECISION_FP32 || E->split) ? 4 : 2;
     E->KG = 64 / E->sz;
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, device));
@@ -2159,7 +2161,7 @@ struct PpgW2v2Body {
 
 int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device, PpgW2v2Body** out) {
     if (!w || !out) return fail(PPG_EINVAL, "null argument");
-    if (precision != PPG_PRECISION_FP32 && precision != PPG_PRECISION_BF16 && precision != PPG_PRECISION_FP16)
+    if (precision != PPG_PRECISION_FP32 && precision != PPG_PRECISION_BF16 && precision != PPG_PRECISION_FP16 && precision != PPG_PRECISION_FP16X2)
         return fail(PPG_EINVAL, "precision %d", precision);
     const int H = w->hidden, F = w->ffn, L = w->num_layers;
     if (H != 768 || w->heads <= 0 || H / w->heads != 64 || H % w->heads) return fail(PPG_EINVAL, "hidden %d / heads %d: the body kernels are built for 768 = 12 x 64", H, w->heads);
@@ -2173,7 +2175,11 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     std::unique_ptr<PpgW2v2Body> m(new PpgW2v2Body());
     PpgEngine* E = &m->eng;
     E->device = device; E->cfg.precision = precision;
-    E->sz = precision == PPG_PRECISION_FP32 ? 4 : 2;
+    // fp16x2: every projection and the attention on fp16 hi + lo operand pairs (PrecX2: the fp32 path's launch sequence
+    // and byte layout, three fp16 MFMAs per product); the positional convolution stays on f32-input MFMAs (its groups
+    // of 48 channels are not whole [32 hi | 32 lo] blocks)
+    E->split = precision == PPG_PRECISION_FP16X2;
+    E->sz = (precision == PPG_PRECISION_FP32 || E->split) ? 4 : 2;
     E->KG = 64 / E->sz;
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, device));
@@ -2210,6 +2216,8 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     if (m->gemm32 && (rc = image(w->proj_weight, H, 512, &m->proj_img))) return rc;
     if ((rc = upload_f32(E, w->proj_bias, H, 0, &m->proj_b))) return rc;
     {   // W'[n][tap * gpt * KG + c] = w[n][c][tap] for c < 48 (n's own group), 0 for the pad channels; plain row order
+        // (fp16x2: as plain fp32 -- this one GEMM runs on the f32-input MFMAs)
+        E->split = false;
         const int taps = m->taps, kk = m->gpt * E->KG;
         const float* pw = w->pos_conv_weight;
         rc = upload_matrix(E, H, taps * kk, H, taps * kk,
@@ -2217,6 +2225,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
                            &m->pos_w);
         if (rc) return rc;
     }
+    E->split = precision == PPG_PRECISION_FP16X2;
     if ((rc = upload_f32(E, w->pos_conv_bias, H, 0, &m->pos_b))) return rc;
     if (const char* v = getenv("PPGS_AMD_W2V2_POSCONV")) m->posconv = atoi(v) != 0;
     if (E->sz != 2 || w->conv_groups != 16 || CG != 48 || m->taps != 128) m->posconv = false;
@@ -2417,9 +2426,10 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
     char* ao = base + L.ao;
     char* hid = base + L.hid;
     const int vt_ld = M + 64;
-    // operand rows of the residual stream: the 16-bit copy, or X itself in fp32 mode
-    const char* act_x = sz == 2 ? Xb : reinterpret_cast<const char*>(X);
-    char* xb_out = sz == 2 ? Xb : nullptr;
+    // operand rows of the residual stream: the 16-bit copy (fp16x2: the [32 hi | 32 lo] copy), or X itself in fp32 mode
+    const bool op_copy = sz == 2 || E->split;
+    const char* act_x = op_copy ? Xb : reinterpret_cast<const char*>(X);
+    char* xb_out = op_copy ? Xb : nullptr;
 
 #define LAUNCH_OK(expr, what)                                                        \
     do {                                                                             \
@@ -2442,7 +2452,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
     };
     // feature projection: LayerNorm(512) -> Linear, rows past the valid frames zeroed (HF: hidden_states[~mask] = 0)
     LAUNCH_OK(ppg::launch_w2v2_layernorm(prec, 512, features, nullptr, m->pn_g, m->pn_b, (long)batch * frames, frames, R, m->eps,
-                                         sz == 2 ? nullptr : reinterpret_cast<float*>(ln), sz == 2 ? ln : nullptr, s), "w2v2 projection LayerNorm");
+                                         op_copy ? nullptr : reinterpret_cast<float*>(ln), op_copy ? ln : nullptr, s), "w2v2 projection LayerNorm");
     if (m->gemm32) {
         // (linear_kernel's 16-token waves re-read the 768 x 512 weights per 64 rows: 205 us for 6.4 GFLOP)
         Gemm32Args g{};
@@ -2462,14 +2472,15 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
             LAUNCH_OK(ppg::launch_posconv(prec, pc, batch, s), "w2v2 positional convolution");
             LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
         } else {
-        LinearArgs a = general(act_x, H, m->pos_w, m->pos_b, H);
+        // (fp16x2: fp32 rows of X against the fp32 weights, on the f32-input MFMAs)
+        LinearArgs a = general(E->split ? reinterpret_cast<const char*>(X) : act_x, H, m->pos_w, m->pos_b, H);
         a.taps = m->taps; a.groups_per_tap = m->gpt; a.real_groups = a.total_groups = m->taps * m->gpt;
         a.act_y_stride = (H / m->groups) * sz; a.act_fn = 2; a.residual = X; a.out32 = P;
         // (32 or 48 tokens per wave -- fewer re-reads of a group's 590 KB of weights -- measured: no faster, 3.20 / 3.24
         // against 3.23 ms per forward: the launch is bound by the re-reads of the ACTIVATION rows, one pass per tap)
         int pos_nt = 1;
         if (const char* v = getenv("PPGS_AMD_W2V2_POS_NT")) pos_nt = std::max(1, std::min(atoi(v), sz == 2 ? 3 : 2));
-        LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 3, pos_nt, a, m->groups, s), "w2v2 positional convolution");
+        LAUNCH_OK(ppg::launch_linear(E->split ? PPG_PRECISION_FP32 : prec, EPI_GENERAL, 3, pos_nt, a, m->groups, s), "w2v2 positional convolution");
         LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
         }
     }
@@ -2517,7 +2528,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         {
             LinearArgs a = general(act_x, H, d.w1, d.b1, F);
             a.act_fn = 2; a.out_ld32 = F;
-            if (sz == 2) { a.out_rows = hid; a.out_ld = F; } else { a.out32 = reinterpret_cast<float*>(hid); }
+            if (op_copy) { a.out_rows = hid; a.out_ld = F; } else { a.out32 = reinterpret_cast<float*>(hid); }
             LAUNCH_OK(ppg::launch_linear(prec, EPI_GENERAL, 16, nt, a, F / 256, s), "w2v2 ffn 1");
             LinearArgs b = general(hid, F, d.w2, d.b2, H);
             b.residual = X; b.out32 = P;

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 const int m = tok0 + 16 * t + idx;
                 if (m >= a.M) continue;
                 const f32x2 lo = gelu_erf_pair(f32x2{acc[nb][t][0], acc[nb][t][1]}), hi = gelu_erf_pair(f32x2{acc[nb][t][2], acc[nb][t][3]});
-                pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1, lo.x, lo.y, hi.x, hi.y);
+                pair[t].put(a.out_rows + (size_t)m * a.out_ld * P::kBytes + P::row_byte(n & ~7), nb & 1, lo.x, lo.y, hi.x, hi.y);
             }
         }
     } else if constexpr (EPI == EPI_GENERAL) {
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256, (NT <= 2 && NB <= 16) ? 2 : 1) void linear_ker
                 if (a.out32) *reinterpret_cast<float4*>(a.out32 + (size_t)m * a.out_ld32 + n) = make_float4(y[0], y[1], y[2], y[3]);
                 if constexpr (NB == 16) {
                     if (a.out_rows) {
-                        if constexpr (P::kIsBF16) pair[t].put(a.out_rows + ((size_t)m * a.out_ld + (n & ~7)) * P::kBytes, nb & 1, y[0], y[1], y[2], y[3]);
+                        if constexpr (P::kIsBF16 || P::kSplit) pair[t].put(a.out_rows + (size_t)m * a.out_ld * P::kBytes + P::row_byte(n & ~7), nb & 1, y[0], y[1], y[2], y[3]);
                         else store4<P>(a.out_rows + ((size_t)m * a.out_ld + n) * P::kBytes, y[0], y[1], y[2], y[3]);
                     }
                 }
@@ -1450,14 +1450,14 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
 // ---------------------------------------------------------------------------
 // Bytes of one K (and one V^T) tile of the attention kernels (four of them in LDS: two DMA double buffers)
 template <class P, int DH>
-constexpr int attn_tile_bytes() { return (P::kSplit && DH == 256) ? 32768 : 16384; }
+constexpr int attn_tile_bytes() { return (P::kSplit && DH == 256) ? 32768 : ((P::kSplit && DH == 64) ? 8192 : 16384); }
 
 template <class P, int NTQ, int DH, int NW>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& item, const int head, char* smem) {
     constexpr int ROWK = DH * P::kBytes;            // K tile row bytes
     constexpr int DG = ROWK / 64;                   // K-groups over head dim
-    // bytes of a K tile and of a V^T tile: 16 KiB; split operands at d = 256: 32 KiB, so that a tile holds a
-    // whole [32 hi | 32 lo] group of keys (one workgroup per CU: 128 KiB of tile buffers)
+    // bytes of a K tile and of a V^T tile: 16 KiB; split operands: ONE [32 hi | 32 lo] group of keys per tile, so
+    // 32 KiB at d = 256 (one workgroup per CU: 128 KiB of tile buffers), 16 KiB at d = 128, 8 KiB at d = 64
     constexpr int TB = attn_tile_bytes<P, DH>();
     constexpr int KT = TB / ROWK;                   // keys per tile
     constexpr int KB = KT / 16;                     // key 16-blocks per tile
@@ -1905,6 +1905,8 @@ hipError_t launch_linear_x2_nt(int epi, int nb, const LinearArgs& a, int ypasses
     case EPI_INCONV:  return launch_linear_t<PrecX2, NT, 16, EPI_INCONV>(a, ypasses, s);
     case EPI_QKV:     return launch_linear_t<PrecX2, NT, 16, EPI_QKV>(a, ypasses, s);
     case EPI_RELU:    return launch_linear_t<PrecX2, NT, 16, EPI_RELU>(a, ypasses, s);
+    case EPI_GELU:    return launch_linear_t<PrecX2, NT, 16, EPI_GELU>(a, ypasses, s);       // wav2vec2 feature encoder
+    case EPI_GENERAL: return nb == 16 ? launch_linear_t<PrecX2, NT, 16, EPI_GENERAL>(a, ypasses, s) : hipErrorInvalidValue;   // wav2vec2 body
     case EPI_OUTCONV: return launch_linear_t<PrecX2, NT, 3, EPI_OUTCONV>(a, ypasses, s);
     case EPI_RESLN:
         if (nb == 16) return launch_linear_t<PrecX2, 1, 16, EPI_RESLN>(a, ypasses, s);
@@ -2003,6 +2005,11 @@ hipError_t launch_attn(int precision, const AttnArgs& args, int nitems, int head
             const hipError_t e = limit.ensure(reinterpret_cast<const void*>(kern), lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(nitems * heads), dim3(256), lds, s, a);
+            return hipGetLastError();
+        }
+        if (head_dim == 64) {        // wav2vec2 body: 32-key tiles of 8 KiB
+            constexpr size_t lds64 = 4 * attn_tile_bytes<PrecX2, 64>();
+            hipLaunchKernelGGL((attn_kernel<PrecX2, 1, 64>), dim3(nitems * heads), dim3(256), lds64, s, a);
             return hipGetLastError();
         }
         if (head_dim != 128) return hipErrorInvalidValue;

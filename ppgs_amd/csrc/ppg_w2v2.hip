@@ -115,7 +115,13 @@ __global__ __launch_bounds__(256) void w2v2_conv0_kernel(const float* audio, lon
             y0 = gy.x; y1 = gy.y;
         }
         if (t0 + t < rows_per_item) {
-            if constexpr (P::kIsBF16) *reinterpret_cast<uint32_t*>(dst + (size_t)t * W2V_C) = P::pack2(y0, y1);
+            if constexpr (P::kSplit) {      // [32 hi | 32 lo] blocks: the pair's hi halves, its lo halves 64 bytes on
+                char* row = out + (((size_t)b * rows_per_item + t0 + t) * W2V_C) * P::kBytes + P::row_byte(c);
+                uint32_t h, l;
+                P::split2(y0, y1, h, l);
+                *reinterpret_cast<uint32_t*>(row) = h;
+                *reinterpret_cast<uint32_t*>(row + 64) = l;
+            } else if constexpr (P::kIsBF16) *reinterpret_cast<uint32_t*>(dst + (size_t)t * W2V_C) = P::pack2(y0, y1);
             else *reinterpret_cast<float2*>(dst + (size_t)t * W2V_C) = make_float2(y0, y1);
         }
     }
@@ -131,7 +137,12 @@ __global__ __launch_bounds__(256) void w2v2_output_kernel(const char* rows, int 
     const int c = (int)(i - t * (W2V_C / 4)) * 4;
     const typename P::elem* src = reinterpret_cast<const typename P::elem*>(rows) + ((size_t)b * rows_per_item + t) * W2V_C + c;
     float4 v;
-    if constexpr (std::is_same_v<P, PrecF32>) {
+    if constexpr (P::kSplit) {
+        const char* at = rows + (((size_t)b * rows_per_item + t) * W2V_C) * P::kBytes + P::row_byte(c);
+        const uint2 h = *reinterpret_cast<const uint2*>(at), l = *reinterpret_cast<const uint2*>(at + 64);
+        auto f = [](uint32_t w, int k) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(k ? w >> 16 : w & 0xffffu)); };
+        v = make_float4(f(h.x, 0) + f(l.x, 0), f(h.x, 1) + f(l.x, 1), f(h.y, 0) + f(l.y, 0), f(h.y, 1) + f(l.y, 1));
+    } else if constexpr (std::is_same_v<P, PrecF32>) {
         v = *reinterpret_cast<const float4*>(src);
     } else {
         const uint2 raw = *reinterpret_cast<const uint2*>(src);
@@ -210,14 +221,8 @@ __global__ __launch_bounds__(256) void w2v2_layernorm_kernel(const float* in32, 
     }
     if (out16) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            typename P::elem* dst = reinterpret_cast<typename P::elem*>(out16) + mo * H + i * 256 + lane * 4;
-            if constexpr (sizeof(typename P::elem) == 2) {
-                *reinterpret_cast<uint2*>(dst) = make_uint2(P::pack2(y[i].x, y[i].y), P::pack2(y[i].z, y[i].w));
-            } else {
-                dst[0] = P::cvt1(y[i].x); dst[1] = P::cvt1(y[i].y); dst[2] = P::cvt1(y[i].z); dst[3] = P::cvt1(y[i].w);
-            }
-        }
+        for (int i = 0; i < PER; ++i)      // (16-bit pairs, fp32, or both planes of the [32 hi | 32 lo] blocks)
+            store4<P>(out16 + (size_t)mo * H * P::kBytes + P::row_byte(i * 256 + lane * 4), y[i].x, y[i].y, y[i].z, y[i].w);
     }
 }
 
@@ -238,6 +243,7 @@ hipError_t launch_w2v2_layernorm(int precision, int H, const float* in32, const 
     };
     if (precision == PPG_PRECISION_BF16) return go(PrecBF16{});
     if (precision == PPG_PRECISION_FP16) return go(PrecF16{});
+    if (precision == PPG_PRECISION_FP16X2) return in16 ? hipErrorInvalidValue : go(PrecX2{});     // (fp32 rows in, split rows out)
     return go(PrecF32{});
 }
 
@@ -253,6 +259,7 @@ hipError_t launch_w2v2_layer0(int precision, const float* audio, int batch, long
     const dim3 grid((rows_per_item + 63) / 64, batch);
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(w2v2_conv0_kernel<PrecBF16>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
     else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(w2v2_conv0_kernel<PrecF16>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
+    else if (precision == PPG_PRECISION_FP16X2) hipLaunchKernelGGL(w2v2_conv0_kernel<PrecX2>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
     else hipLaunchKernelGGL(w2v2_conv0_kernel<PrecF32>, grid, dim3(256), 0, s, audio, samples, frames, rows_per_item, w0, scale_shift, out);
     return hipGetLastError();
 }
@@ -261,6 +268,7 @@ hipError_t launch_w2v2_output(int precision, const char* rows, int batch, int ro
     const dim3 grid((unsigned)((frames * (W2V_C / 4) + 255) / 256), batch);
     if (precision == PPG_PRECISION_BF16) hipLaunchKernelGGL(w2v2_output_kernel<PrecBF16>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
     else if (precision == PPG_PRECISION_FP16) hipLaunchKernelGGL(w2v2_output_kernel<PrecF16>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
+    else if (precision == PPG_PRECISION_FP16X2) hipLaunchKernelGGL(w2v2_output_kernel<PrecX2>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
     else hipLaunchKernelGGL(w2v2_output_kernel<PrecF32>, grid, dim3(256), 0, s, rows, rows_per_item, frames, out);
     return hipGetLastError();
 }

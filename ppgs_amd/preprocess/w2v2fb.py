@@ -54,11 +54,14 @@ def model_for(device):
 
 
 def w2v2_precision():
-    """Operand precision of the wav2vec2 engines for the package's PRECISION: they have fp32 and 16-bit forms only,
-    so 'fp16x2' (every PPG-network operand an fp16 hi + lo pair, <= 1e-4) runs them in their own <= 1e-4 form,
-    fp32 -- the whole w2v2fb path then stays inside the parity bar, with the PPG network at a third of its fp32 time."""
+    """Operand precision of the wav2vec2 engines for the package's PRECISION: the same mode.  'fp16x2' (<= 1e-4)
+    runs the feature encoder's six GEMM layers, every projection of the body and its attention on fp16 hi + lo operand
+    pairs (the positional convolution on f32-input MFMAs); PPGS_AMD_W2V2_FP32=1 runs the wav2vec2 engines of that mode
+    in fp32 instead (the route until round 5: 2.3 x slower)."""
     from .. import core
-    return 'fp32' if core.PRECISION == 'fp16x2' else core.PRECISION
+    if core.PRECISION == 'fp16x2' and os.environ.get('PPGS_AMD_W2V2_FP32', '0') == '1':
+        return 'fp32'
+    return core.PRECISION
 
 
 def feature_encoder_for(device, model):
@@ -110,7 +113,7 @@ def last_hidden_state(model, padded, mask):
     # PPGS_AMD_W2V2_BODY=0: the HF modules on PyTorch-ROCm; in the 16-bit engine modes under fp16
     # autocast, which is how the reference itself runs the whole model on a GPU
     # (ppgs/preprocess/core.py:207: torch.autocast('cuda')); fp32 engine mode: fp32 throughout
-    with torch.autocast('cuda', dtype=torch.float16, enabled=w2v2_precision() != 'fp32'):
+    with torch.autocast('cuda', dtype=torch.float16, enabled=w2v2_precision() not in ('fp32', 'fp16x2')):
         hidden, _ = model.feature_projection(extract)
         out = model.encoder(hidden, attention_mask=attention_mask).last_hidden_state
     return out.float()

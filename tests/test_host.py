@@ -320,13 +320,18 @@ def test_w2v2fb_engines_follow_the_package_precision(monkeypatch):
     w2v2fb.clear()
     device = torch.device('cuda', 0)
     model = types.SimpleNamespace(feature_extractor=types.SimpleNamespace(state_dict=lambda: {}))
-    for precision, expected in (('fp16x2', 'fp32'), ('fp32', 'fp32'), ('fp16', 'fp16'), ('bf16', 'bf16')):
+    for precision, expected in (('fp16x2', 'fp16x2'), ('fp32', 'fp32'), ('fp16', 'fp16'), ('bf16', 'bf16')):
         monkeypatch.setattr(core, 'PRECISION', precision)
         assert w2v2fb.w2v2_precision() == expected
         w2v2fb.feature_encoder_for(device, model)
         w2v2fb.body_for(device, model)
-    # fp16x2 and fp32 share one pair of engines
-    assert built == ['fp32', 'fp32', 'fp16', 'fp16', 'bf16', 'bf16']
+    assert built == ['fp16x2', 'fp16x2', 'fp32', 'fp32', 'fp16', 'fp16', 'bf16', 'bf16']
+    # PPGS_AMD_W2V2_FP32=1: the wav2vec2 engines of the fp16x2 mode in fp32 (the route until round 5) -- the fp32 mode's pair
+    monkeypatch.setenv('PPGS_AMD_W2V2_FP32', '1')
+    monkeypatch.setattr(core, 'PRECISION', 'fp16x2')
+    assert w2v2fb.w2v2_precision() == 'fp32'
+    w2v2fb.feature_encoder_for(device, model)
+    assert len(built) == 8
     w2v2fb.clear()
 
 
