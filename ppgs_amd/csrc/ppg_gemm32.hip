@@ -222,11 +222,24 @@ __device__ __forceinline__ void gemm32_body(const Gemm32Args& a, char* smem) {
             for (int t = 0; t < GT; ++t) {
                 if (m0 + 32 * t >= a.M) continue;
                 const f32x16& c = acc[rb][t];
+                // (as ppg_layer32.h qkv_tail: the block's two halves after one v_permlane16_swap per dword -- an
+                // instruction writes 16 V^T rows x 64 contiguous bytes instead of 32 rows x 32)
+                u32x4 half[2], lo, hi;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    *reinterpret_cast<u32x4*>(rowp + (size_t)(m0 + 32 * t + 16 * s2 + 8 * hh) * 2) = u32x4{
+                    half[s2] = u32x4{
                         P::pack2(c[4 * s2 + 0] + bv[rb], c[4 * s2 + 1] + bv[rb]), P::pack2(c[4 * s2 + 2] + bv[rb], c[4 * s2 + 3] + bv[rb]),
                         P::pack2(c[4 * (s2 + 2) + 0] + bv[rb], c[4 * (s2 + 2) + 1] + bv[rb]), P::pack2(c[4 * (s2 + 2) + 2] + bv[rb], c[4 * (s2 + 2) + 3] + bv[rb])};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(half[0][d], half[1][d], false, false);
+                    lo[d] = sw[0]; hi[d] = sw[1];
+                }
+                // lane rows 0 .. 3 hold the 16-byte pieces 0, 2, 1, 3 of the 32 columns of V^T row (l & 15) resp. 16 + (l & 15)
+                const int k16 = lane >> 4;
+                char* dst = rowp + ((ptrdiff_t)((lane & 15) - tok) * a.vt_ld + m0 + 32 * t) * 2 + 16 * (2 * (k16 & 1) + (k16 >> 1));
+                *reinterpret_cast<u32x4*>(dst) = lo;
+                *reinterpret_cast<u32x4*>(dst + (size_t)16 * a.vt_ld * 2) = hi;
             }
         }
         GSTAMP(7);

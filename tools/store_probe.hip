@@ -38,6 +38,28 @@ __global__ __launch_bounds__(256, 2) void probe(char* out, int M, int ld, int re
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 *reinterpret_cast<u32x4*>(base + (size_t)(4 * (j >> 1) + (lane >> 4)) * ld + (j & 1) * 256 + (lane & 15) * 16) = u32x4{v, v, v, v};
+        } else if constexpr (PATTERN == 5) {   // 32x32 accumulator layout (ppg_layer32.h qkv_tail): 32 rows x 2 pieces of 16 B, 32 B apart
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    *reinterpret_cast<u32x4*>(base + (size_t)(lane & 31) * ld + fb * 64 + (lane >> 5) * 32 + s2 * 16) = u32x4{v, v, v, v};
+        } else if constexpr (PATTERN == 6) {   // the same data after a v_permlane16_swap per dword: 16 rows x 64 B per instruction
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 w = u32x4{v, v, v, v};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { auto r = __builtin_amdgcn_permlane16_swap(w[d], w[d] + 1, false, false); w[d] = r[s2]; }
+                    *reinterpret_cast<u32x4*>(base + (size_t)(16 * s2 + (lane & 15)) * ld + fb * 64 + (lane >> 4) * 16) = w;
+                }
+        } else if constexpr (PATTERN == 7) {   // V^T of the 32x32 layout: 32 rows (one per lane & 31), 32 B per row and instruction, rows far apart
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    *reinterpret_cast<u32x4*>(out + ((size_t)(blockIdx.y * 256 + fb * 32 + (lane & 31)) * (size_t)(M + 64) + tok0) * 2 + s2 * 32 + (lane >> 5) * 16) = u32x4{v, v, v, v};
         } else if constexpr (PATTERN == 4) {   // 8 rows x 128 B per instruction
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -98,6 +120,11 @@ int main() {
     run_sparse<2>("acc layout 16 B/lane (16 rows x 64 B)", out, M, ld, 3);
     run_sparse<4>("8 rows x 128 B per instruction", out, M, ld, 3);
     run_sparse<1>("2 rows x 512 B per instruction", out, M, ld, 3);
+    run_sparse<5>("32x32 acc layout (32 rows x 2 x 16 B)", out, M, ld, 3);
+    run_sparse<6>("... after permlane16_swap (16 rows x 64 B)", out, M, ld, 3);
+    run_sparse<7>("V^T rows of the 32x32 layout (32 rows x 32 B)", out, M, ld, 3);
+    run_sparse<5>("32x32 acc layout (32 rows x 2 x 16 B)", out, M, ld, 3);
+    run_sparse<6>("... after permlane16_swap (16 rows x 64 B)", out, M, ld, 3);
     hipFree(out);
     return 0;
 }
