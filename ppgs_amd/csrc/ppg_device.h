@@ -98,6 +98,16 @@ struct PrecBF16 {
     static __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    // ... with the accumulator in ARCHITECTURAL registers (see ppg_layer32.hip, phase A: a kernel that may use all 512
+    // registers gets the accumulation-register form for every builtin MFMA, and VALU consumers of a result then pay one
+    // v_accvgpr_read per value).  Inline asm: the compiler inserts no wait states around it -- the caller keeps a result's
+    // first VALU read at least two other MFMAs behind the MFMA that wrote it.
+    static __device__ __forceinline__ void mma32v0(f32x16& d, const u32x4& a, const u32x4& b, const f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    }
+    static __device__ __forceinline__ void mma32v(f32x16& d, const u32x4& a, const u32x4& b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    }
 };
 
 struct PrecF16 {
@@ -125,6 +135,12 @@ struct PrecF16 {
     static __device__ __forceinline__ uint32_t relu2(uint32_t packed) { return relu_packed16(packed); }
     static __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma32v0(f32x16& d, const u32x4& a, const u32x4& b, const f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    }
+    static __device__ __forceinline__ void mma32v(f32x16& d, const u32x4& a, const u32x4& b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
 };
 

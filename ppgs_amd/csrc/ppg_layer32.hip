@@ -30,6 +30,22 @@
 // accumulator of one GEMM is the operand of the next after ONE ds_write_b128.
 #include "ppg_layer32.h"
 
+// phase A of the hidden-256 chunk loop: h in architectural registers (inline-asm MFMAs), or -- -DPPG_L32_H_IN_ACC, the
+// form until round 5, kept for A/B builds -- wherever the compiler puts a builtin MFMA's result
+#ifdef PPG_L32_H_IN_ACC
+#define PPG_MMA_H0(d, a, b, c) (d) = P::mma32((a), (b), (c))
+#define PPG_MMA_H(d, a, b) (d) = P::mma32((a), (b), (d))
+#define PPG_W2SET w2f
+#define PPG_W2LOAD gload_frag
+#define PPG_W2PIN "+v"
+#else
+#define PPG_MMA_H0(d, a, b, c) P::mma32v0((d), (a), (b), (c))
+#define PPG_MMA_H(d, a, b) P::mma32v((d), (a), (b))
+#define PPG_W2SET w2a
+#define PPG_W2LOAD gload_frag_acc
+#define PPG_W2PIN "+a"
+#endif
+
 namespace {
 
 template <class P, int HIDT, bool QKV, int TBS = tile_blocks(HIDT)>
@@ -430,7 +446,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // step 98's -- the barriers sit exactly there.  A wave's own ds_writes are complete at its barrier: LDS operations
         // complete in order and the wave has since waited for ring reads it requested after them.  h of blocks 0..2 is
         // overwritten 70 steps after barrier Y of the previous chunk, h of blocks 3, 4 after barrier X of this one.
+        // Register files (round 5).  A kernel that may use all 512 registers gets the ACCUMULATION-register form for every
+        // builtin MFMA; h, whose consumers are VALU instructions (pack, ReLU), then cost one v_accvgpr_read per value and
+        // one v_accvgpr_write per bias value: 96 of a chunk's 180 VALU instructions, all of them in the hand-over's
+        // clumps.  Phase A therefore runs on inline-asm MFMAs whose accumulators are architectural registers, and this
+        // chunk's W2 fragments live in accumulation registers instead (w2a: loaded there directly, read from there by the
+        // builtin MFMAs of phase B) -- the 64 architectural registers of w2f are h's for the duration of the loop.
+        // The compiler inserts no wait states around an asm MFMA: a block's h is first read (h_write) at least four
+        // MFMAs after the MFMA that completed it, and b1 comes straight from LDS reads behind their wait.
         u32x4 braw[4];
+        u32x4 w2a[16];
         bias_read(braw, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int c = 0; c < ((PPG_DBG(a) & 2) ? 0 : NCH); ++c) {
@@ -467,21 +492,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 48) {
                     constexpr int ks = i / 3, tb = i % 3;
-                    if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-                    else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
-                    if constexpr (i % 3 == 1) gload_frag<i / 3>(w2f[i / 3], voff, w2c);
+                    if constexpr (ks == 0) PPG_MMA_H0(hacc[tb], w1f[0], bf, bias);
+                    else PPG_MMA_H(hacc[tb], w1f[ks], bf);
+                    if constexpr (i % 3 == 1) PPG_W2LOAD<i / 3>(PPG_W2SET[i / 3], voff, w2c);
                 } else if constexpr (i < 80) {
                     constexpr int j = i - 48, ks = j / 2, tb = 3 + j % 2;
                     if constexpr (j == 0) cstamp(1);
-                    if constexpr (ks == 0) hacc[tb] = P::mma32(w1f[0], bf, bias);
-                    else hacc[tb] = P::mma32(w1f[ks], bf, hacc[tb]);
+                    if constexpr (ks == 0) PPG_MMA_H0(hacc[tb], w1f[0], bf, bias);
+                    else PPG_MMA_H(hacc[tb], w1f[ks], bf);
+                    // (b1 is the C operand of step 49's MFMA, which reads it over its passes: the registers stay b1's until
+                    // that MFMA is done -- the compiler, blind to the asm, handed them to the next instruction otherwise)
+                    if constexpr (j == 4) asm volatile("" :: "v"(bias));
                     if constexpr (j % 3 == 2 && j / 3 < 6) h_write(std::integral_constant<int, (j / 3) / 2>{}, std::integral_constant<int, (j / 3) % 2>{});
                     if constexpr (i == 74) asm volatile("s_barrier" ::: "memory");
                 } else if constexpr (i < 104) {
                     constexpr int j = i - 80, ks = j / 3, tb = j % 3;
-                    if constexpr (j == 0) { cstamp(2); vm_wait_all(w2f); }
-                    yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
-                    yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                    if constexpr (j == 0) {
+                        cstamp(2);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this chunk's W2 fragments have landed
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) asm volatile("" : PPG_W2PIN(PPG_W2SET[k]));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    yacc[0][tb] = P::mma32(PPG_W2SET[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(PPG_W2SET[8 + ks], bf, yacc[1][tb]);
                     if constexpr (j < 16) gload_frag<j>(w1f[j], voff, next1);
                     if constexpr (j % 2 == 1 && j / 2 < 4) h_write(std::integral_constant<int, 3 + (j / 2) / 2>{}, std::integral_constant<int, (j / 2) % 2>{});
                     if constexpr (j == 17) bias_read(braw, cn);
@@ -489,8 +523,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 } else {
                     constexpr int j = i - 104, ks = j / 2, tb = 3 + j % 2;
                     if constexpr (j == 0) cstamp(3);
-                    yacc[0][tb] = P::mma32(w2f[ks], bf, yacc[0][tb]);
-                    yacc[1][tb] = P::mma32(w2f[8 + ks], bf, yacc[1][tb]);
+                    yacc[0][tb] = P::mma32(PPG_W2SET[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(PPG_W2SET[8 + ks], bf, yacc[1][tb]);
                 }
             });
             cstamp(5);
