@@ -221,17 +221,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    [[maybe_unused]] uint32_t w4[4] = {0u, 0u, 0u, 0u};
                     if constexpr (RES && XH) {          // X16 order: one contiguous KiB of fp16 per load instruction
                         u32x4 rv;
                         if constexpr (XPRE) rv = res[(t * RB + rb) * 2 + s2];          // (requested at the top of the kernel)
                         else rv = *reinterpret_cast<const u32x4*>(xh + ((gblock(t) * RB + rb) * 2 + s2) * 1024);
-                        const uint32_t w4[4] = {rv.x, rv.y, rv.z, rv.w};
+                        w4[0] = rv.x; w4[1] = rv.y; w4[2] = rv.z; w4[3] = rv.w;
+#ifdef PPG_L32_LN_OLD
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const f16x2 pr = __builtin_bit_cast(f16x2, w4[j]);
                             r8[2 * j] = (float)pr[0];
                             r8[2 * j + 1] = (float)pr[1];
                         }
+#endif
                     } else if constexpr (RES) {         // X32 order: one contiguous KiB per load instruction
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
@@ -244,8 +247,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const int q = 2 * s2 + e;
                         float4 bv;
                         if constexpr (KEEP) bv = bias4[rb][q]; else bv = quad(0, rb, q);
+#ifndef PPG_L32_LN_OLD
+                        if constexpr (RES && XH) {
+                            // acc + bias + fp16 residual: the conversion rides in the add (v_fma_mix_f32: src0 an fp16 half
+                            // selected by op_sel, times 1.0, plus an fp32)
+                            const float bq4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float sum = yacc[rb][t][4 * q + k] + bq4[k];
+                                float out;
+                                if (k & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w4[2 * e + k / 2]), "v"(sum));
+                                else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(out) : "v"(w4[2 * e + k / 2]), "v"(sum));
+                                yacc[rb][t][4 * q + k] = out;
+                            }
+                        } else
+#endif
+                        {
                         yacc[rb][t][4 * q + 0] += bv.x + r8[4 * e + 0]; yacc[rb][t][4 * q + 1] += bv.y + r8[4 * e + 1];
                         yacc[rb][t][4 * q + 2] += bv.z + r8[4 * e + 2]; yacc[rb][t][4 * q + 3] += bv.w + r8[4 * e + 3];
+                        }
                         stat4(sum2, sq2, yacc[rb][t][4 * q + 0], yacc[rb][t][4 * q + 1], yacc[rb][t][4 * q + 2], yacc[rb][t][4 * q + 3]);
                     }
                 }
@@ -270,7 +290,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float* s = stats + 32 * t + tok;
             const float mean = ((s[0] + s[TOKS]) + (s[2 * TOKS] + s[3 * TOKS])) * (1.0f / HIDT);
             const float ex2 = ((s[4 * TOKS] + s[5 * TOKS]) + (s[6 * TOKS] + s[7 * TOKS])) * (1.0f / HIDT);
+#ifdef PPG_L32_LN_OLD
             const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + kLnEps32);
+#else
+            // (v_rsq_f32, 1 ulp: the IEEE division and square root are ~30 instructions per token block of a phase
+            // in which the matrix pipe idles)
+            const float rstd = __builtin_amdgcn_rsqf(fmaxf(ex2 - mean * mean, 0.f) + kLnEps32);
+#endif
             const float shift = -mean * rstd;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -488,6 +514,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
                 asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
             };
+            // ... in two halves on two consecutive single-MFMA steps of phase A (3, 4): a whole unit -- 4 packs, 4 ReLUs, the
+            // write -- is 40 issue cycles behind an MFMA that hides 32
+            uint32_t hlo0 = 0, hlo1 = 0;
+            auto h_half = [&](auto t_tag, auto s_tag, auto part_tag) {
+                constexpr int t = decltype(t_tag)::value, s2 = decltype(s_tag)::value, part = decltype(part_tag)::value;
+                if constexpr (part == 0) {
+                    hlo0 = P::relu2(P::pack2(hacc[t][8 * s2 + 0], hacc[t][8 * s2 + 1]));
+                    hlo1 = P::relu2(P::pack2(hacc[t][8 * s2 + 2], hacc[t][8 * s2 + 3]));
+                } else {
+                    const u32x4 frag = u32x4{hlo0, hlo1, P::relu2(P::pack2(hacc[t][8 * s2 + 4], hacc[t][8 * s2 + 5])), P::relu2(P::pack2(hacc[t][8 * s2 + 6], hacc[t][8 * s2 + 7]))};
+                    const uint32_t addr = hb0 + (uint32_t)((t * 8 + 2 * wave + s2) * 1024);
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(frag) : "memory");
+                }
+            };
             stream<OffChunk256, 120, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 48) {
@@ -503,7 +543,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // (b1 is the C operand of step 49's MFMA, which reads it over its passes: the registers stay b1's until
                     // that MFMA is done -- the compiler, blind to the asm, handed them to the next instruction otherwise)
                     if constexpr (j == 4) asm volatile("" :: "v"(bias));
+#ifdef PPG_L32_UNITS_OLD
                     if constexpr (j % 3 == 2 && j / 3 < 6) h_write(std::integral_constant<int, (j / 3) / 2>{}, std::integral_constant<int, (j / 3) % 2>{});
+#else
+                    // unit k = (block k / 2, half k % 2) as two half-units on the steps j = 3 k + 2, 3 k + 3.  The last write is at
+                    // j = 18 (step 66): a wave's LDS operations complete in order, and by barrier X (step 74) it has waited for the
+                    // ring read it issued behind that write (step 66's, awaited at step 72).
+                    if constexpr (j >= 2 && (j - 2) % 3 < 2 && (j - 2) / 3 < 6)
+                        h_half(std::integral_constant<int, ((j - 2) / 3) / 2>{}, std::integral_constant<int, ((j - 2) / 3) % 2>{}, std::integral_constant<int, (j - 2) % 3>{});
+#endif
                     if constexpr (i == 74) asm volatile("s_barrier" ::: "memory");
                 } else if constexpr (i < 104) {
                     constexpr int j = i - 80, ks = j / 3, tb = j % 3;
@@ -517,7 +565,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     yacc[0][tb] = P::mma32(PPG_W2SET[ks], bf, yacc[0][tb]);
                     yacc[1][tb] = P::mma32(PPG_W2SET[8 + ks], bf, yacc[1][tb]);
                     if constexpr (j < 16) gload_frag<j>(w1f[j], voff, next1);
+#ifdef PPG_L32_UNITS_OLD
                     if constexpr (j % 2 == 1 && j / 2 < 4) h_write(std::integral_constant<int, 3 + (j / 2) / 2>{}, std::integral_constant<int, (j / 2) % 2>{});
+#else
+                    // the four units of blocks 3, 4 on the steps j = 1, 4, 7, 10 (two MFMAs each: a unit fits).  The last write
+                    // is at step 90; barrier Y (step 98) comes behind the wait for step 90's ring read (awaited at step 96).
+                    if constexpr (j % 3 == 1 && j / 3 < 4) h_write(std::integral_constant<int, 3 + (j / 3) / 2>{}, std::integral_constant<int, (j / 3) % 2>{});
+#endif
                     if constexpr (j == 17) bias_read(braw, cn);
                     if constexpr (i == 98) asm volatile("s_barrier" ::: "memory");
                 } else {
