@@ -246,6 +246,30 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             b4[0] = make_float4(bv, bv, bv, bv);
         }
     };
+    // The bias is the C operand of a step's first MFMAs (-DPPG_TAIL_BIAS_IN_UNIT: added in the epilogue units, the form
+    // until round 5 -- 16 v_add_f32 per unit pair in slots that hide ~8 instructions each)
+#ifdef PPG_TAIL_BIAS_IN_UNIT
+    auto bias_in_unit = [](float b) { return b; };
+#else
+    auto bias_in_unit = [](float) { return -0.0f; };            // (x + -0.0f folds away; x + 0.0f does not: -0 + 0 = +0)
+#endif
+    auto bias_c = [&](auto step_tag) {
+        constexpr int STEP = decltype(step_tag)::value;
+        f32x16 cinit = zero;
+#ifndef PPG_TAIL_BIAS_IN_UNIT
+        float4 bb[4];
+        bias_of(step_tag, bb);
+        if constexpr (STEP / RB < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cinit[4 * q + 0] = bb[q].x; cinit[4 * q + 1] = bb[q].y; cinit[4 * q + 2] = bb[q].z; cinit[4 * q + 3] = bb[q].w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cinit[k] = bb[0].x;
+        }
+#endif
+        return cinit;
+    };
+    u32x4 held = u32x4{0u, 0u, 0u, 0u};
     // epilogue unit U (token block U / 2, half U % 2) of step STEP from its accumulator set
     auto unit = [&](auto step_tag, auto u_tag, const float4 (&b4)[4]) {
         constexpr int STEP = decltype(step_tag)::value, U = decltype(u_tag)::value;
@@ -257,24 +281,27 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         // bytes apart); swapping the 16-lane rows of the two packed registers gives one register the four 16-byte
         // pieces of rows 0 .. 15 and the other those of rows 16 .. 31 -- an instruction then writes 16 rows x 64
         // CONTIGUOUS bytes (tools/store_probe.hip, every CU storing: 4.67 -> 5.21 TB/s for Q | K, 4.30 -> 5.2 for V^T).
-        // Both stores ride on the even unit; the odd unit is empty (the count of stores per step stays NU).
+        // The even unit packs the first half (kept in `held`), the odd unit packs the second, swaps and stores both:
+        // the count of stores per step stays NU, and neither slot carries more than ~14 VALU instructions.
         if (regular) {
+            u32x4 r;
+            if constexpr (KIND < 2) {
+                r = u32x4{P::pack2(c[8 * s2 + 0] + bias_in_unit(b4[2 * s2].x), c[8 * s2 + 1] + bias_in_unit(b4[2 * s2].y)),
+                          P::pack2(c[8 * s2 + 2] + bias_in_unit(b4[2 * s2].z), c[8 * s2 + 3] + bias_in_unit(b4[2 * s2].w)),
+                          P::pack2(c[8 * s2 + 4] + bias_in_unit(b4[2 * s2 + 1].x), c[8 * s2 + 5] + bias_in_unit(b4[2 * s2 + 1].y)),
+                          P::pack2(c[8 * s2 + 6] + bias_in_unit(b4[2 * s2 + 1].z), c[8 * s2 + 7] + bias_in_unit(b4[2 * s2 + 1].w))};
+            } else {
+                const float bv = bias_in_unit(b4[0].x);
+                r = u32x4{P::pack2(c[4 * s2 + 0] + bv, c[4 * s2 + 1] + bv), P::pack2(c[4 * s2 + 2] + bv, c[4 * s2 + 3] + bv),
+                          P::pack2(c[4 * (s2 + 2) + 0] + bv, c[4 * (s2 + 2) + 1] + bv), P::pack2(c[4 * (s2 + 2) + 2] + bv, c[4 * (s2 + 2) + 3] + bv)};
+            }
             if constexpr (s2 == 0) {
-                u32x4 r0, r1;
-                if constexpr (KIND < 2) {
-                    r0 = u32x4{P::pack2(c[0] + b4[0].x, c[1] + b4[0].y), P::pack2(c[2] + b4[0].z, c[3] + b4[0].w),
-                               P::pack2(c[4] + b4[1].x, c[5] + b4[1].y), P::pack2(c[6] + b4[1].z, c[7] + b4[1].w)};
-                    r1 = u32x4{P::pack2(c[8] + b4[2].x, c[9] + b4[2].y), P::pack2(c[10] + b4[2].z, c[11] + b4[2].w),
-                               P::pack2(c[12] + b4[3].x, c[13] + b4[3].y), P::pack2(c[14] + b4[3].z, c[15] + b4[3].w)};
-                } else {
-                    const float bv = b4[0].x;
-                    r0 = u32x4{P::pack2(c[0] + bv, c[1] + bv), P::pack2(c[2] + bv, c[3] + bv), P::pack2(c[8] + bv, c[9] + bv), P::pack2(c[10] + bv, c[11] + bv)};
-                    r1 = u32x4{P::pack2(c[4] + bv, c[5] + bv), P::pack2(c[6] + bv, c[7] + bv), P::pack2(c[12] + bv, c[13] + bv), P::pack2(c[14] + bv, c[15] + bv)};
-                }
+                held = r;
+            } else {
                 u32x4 lo, hi;                 // rows (l & 15) and 16 + (l & 15) of the block
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(r0[d], r1[d], false, false);
+                    const auto sw = __builtin_amdgcn_permlane16_swap(held[d], r[d], false, false);
                     lo[d] = sw[0]; hi[d] = sw[1];
                 }
                 const int r16 = lane & 15, k16 = lane >> 4;
@@ -284,7 +311,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
                     *reinterpret_cast<u32x4*>(dst) = lo;
                     *reinterpret_cast<u32x4*>(dst + (size_t)16 * 2 * HIDT * 2) = hi;
                 } else {
-                    // (r0, r1) = the column pieces (8 hh, 16 + 8 hh): lane rows 0 .. 3 hold the pieces 0, 2, 1, 3 of the 32 columns
+                    // (held, r) = the column pieces (8 hh, 16 + 8 hh): lane rows 0 .. 3 hold the pieces 0, 2, 1, 3 of the 32 columns
                     char* dst = a.vt_out + ((size_t)(fbase + 32 * RBI + r16) * a.vt_ld + vcol[t][0]) * 2 + 16 * (2 * (k16 & 1) + (k16 >> 1));
                     *reinterpret_cast<u32x4*>(dst) = lo;
                     *reinterpret_cast<u32x4*>(dst + (size_t)16 * a.vt_ld * 2) = hi;
@@ -300,14 +327,14 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
                 char* dst = a.qk_out + ((size_t)m * 2 * HIDT + HIDT * KIND + 32 * RBI + fbase + 16 * hh) * 2;
                 const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
                 *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{
-                    P::pack2(c[8 * s2 + 0] + ba.x, c[8 * s2 + 1] + ba.y), P::pack2(c[8 * s2 + 2] + ba.z, c[8 * s2 + 3] + ba.w),
-                    P::pack2(c[8 * s2 + 4] + bb.x, c[8 * s2 + 5] + bb.y), P::pack2(c[8 * s2 + 6] + bb.z, c[8 * s2 + 7] + bb.w)};
+                    P::pack2(c[8 * s2 + 0] + bias_in_unit(ba.x), c[8 * s2 + 1] + bias_in_unit(ba.y)), P::pack2(c[8 * s2 + 2] + bias_in_unit(ba.z), c[8 * s2 + 3] + bias_in_unit(ba.w)),
+                    P::pack2(c[8 * s2 + 4] + bias_in_unit(bb.x), c[8 * s2 + 5] + bias_in_unit(bb.y)), P::pack2(c[8 * s2 + 6] + bias_in_unit(bb.z), c[8 * s2 + 7] + bias_in_unit(bb.w))};
             }
         } else {
             // V: lane = V^T row fbase + 32 RBI + (l & 31) (natural feature pair_row(row): attn_kernel's tile order),
             // registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of every 32-token group
             // of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
-            const float bv = b4[0].x;
+            const float bv = bias_in_unit(b4[0].x);
             char* rowp = a.vt_out + (size_t)(fbase + 32 * RBI + tok) * a.vt_ld * 2;
             if (valigned[t]) {            // the block is one 32-token group: (q, q + 2) are 8 consecutive columns
                 *reinterpret_cast<u32x4*>(rowp + (size_t)(vcol[t][0] + 16 * s2 + 8 * hh) * 2) = u32x4{
@@ -323,7 +350,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             }
         }
     };
-    float4 b4[4];
+    float4 b4[4] = {};
     auto half_step = [&](auto hs_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
         constexpr int HS = decltype(hs_tag)::value;
         constexpr int STEP = HS / KH, kh = HS % KH;
@@ -331,6 +358,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         constexpr bool LAST = HS + 1 == NHS;
         constexpr bool EPI = kh == 0 && STEP > 0;            // the previous step's epilogue rides along
         const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
+#ifdef PPG_TAIL_BIAS_IN_UNIT
         if constexpr (EPI) {
             // (LDS reads by compiler code: waited for HERE, not in the middle of the stream where the compiler's
             // lgkmcnt(0) would drain the fragment ring)
@@ -338,11 +366,19 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
 #pragma unroll
             for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(b4[q].x), "+v"(b4[q].y), "+v"(b4[q].z), "+v"(b4[q].w));
         }
+#endif
+        // this step's bias: the C operand of its first MFMAs (LDS reads by compiler code, waited for HERE)
+        f32x16 cinit = zero;
+        if constexpr (kh == 0) {
+            cinit = bias_c(std::integral_constant<int, STEP>{});
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(cinit[k]));
+        }
         f32x16 (&c)[TB] = acc[STEP & 1];
         stream<OffPanel<KS, 16 * kh, 0, TB>, NMMA, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
             constexpr int ks = i / TB, tb = i % TB;
-            if constexpr (ks == 0 && kh == 0) c[tb] = SWAP ? P::mma32(bf, cur[0], zero) : P::mma32(cur[0], bf, zero);
+            if constexpr (ks == 0 && kh == 0) c[tb] = SWAP ? P::mma32(bf, cur[0], cinit) : P::mma32(cur[0], bf, cinit);
             else c[tb] = SWAP ? P::mma32(bf, cur[ks], c[tb]) : P::mma32(cur[ks], bf, c[tb]);
             // the next half-step's fragments first, the previous step's stores behind them
             if constexpr (!LAST && i < 16) gload_frag<i>(nxt[i], voff, nbase);
@@ -368,7 +404,9 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
                      : half_step(std::integral_constant<int, S>{}, w2f, w1f)), ...);
     }(std::make_integer_sequence<int, NHS>{});
     // the last step's epilogue
+#ifdef PPG_TAIL_BIAS_IN_UNIT
     bias_of(std::integral_constant<int, NSTEP - 1>{}, b4);
+#endif
     (void)TOKS;
     [&]<int... U>(std::integer_sequence<int, U...>) {
         (unit(std::integral_constant<int, NSTEP - 1>{}, std::integral_constant<int, U>{}, b4), ...);
