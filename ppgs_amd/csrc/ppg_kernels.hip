@@ -1634,6 +1634,35 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         }
     };
 
+    // Three-stage loop of the 16-bit modes (round 5): iteration kt computes the scores of tile kt + 2, exponentiates tile
+    // kt + 1 and accumulates tile kt -- the exponentials of a tile no longer have to fit between the MFMAs of ONE
+    // phase (they rode on the score MFMAs only, clumped ~14 instructions to a step, while the P V MFMAs ran bare), they
+    // are spread as micro-operations (two exponentials, their sum, one pack) over BOTH phases, one to every other step.
+#ifdef PPG_ATTN_2STAGE
+    constexpr bool STAGE3 = false;
+#else
+    constexpr bool STAGE3 = P::kIsBF16 && !P::kSplit && NTQ == 1;      // (32 queries per wave: 256 registers do not hold a third tile's state)
+#endif
+    // micro-operation u = (t, kb, h): p of the scores 2 h, 2 h + 1 of key block kb for query block t
+    constexpr int NUOP = NTQ * KB * 2;
+    auto exp_half = [&](auto u_tag, f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
+        constexpr int u = decltype(u_tag)::value, t = u / (2 * KB), kb = (u / 2) % KB, h = u % 2;
+        const float p0 = __builtin_amdgcn_exp2f(s[kb][t][2 * h]), p1 = __builtin_amdgcn_exp2f(s[kb][t][2 * h + 1]);
+        psum[t] += p0 + p1;
+        const uint32_t w = P::pack2(p0, p1);
+        if constexpr ((kb & 1) == 0 && h == 0) pf[kb >> 1][t].x = w;
+        else if constexpr ((kb & 1) == 0) pf[kb >> 1][t].y = w;
+        else if constexpr (h == 0) pf[kb >> 1][t].z = w;
+        else pf[kb >> 1][t].w = w;
+    };
+    // the micro-operations of global step G of NS: [ceil(G NUOP / NS), ceil((G + 1) NUOP / NS))
+    auto exp_ops = [&]<int G, int NS>(f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
+        constexpr int lo = (G * NUOP + NS - 1) / NS, hi = ((G + 1) * NUOP + NS - 1) / NS;
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            (exp_half(std::integral_constant<int, lo + U>{}, s, pf), ...);
+        }(std::make_integer_sequence<int, hi - lo>{});
+    };
+
     if (ntiles > 0) { stage_k(0); stage_v(0); }
     if (ntiles > 1) stage_k(1);
     dma_wait_barrier();
@@ -1669,6 +1698,92 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 #ifdef PPG_ATTN_TIMING
     const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();   // prologue done (Q, first tiles, first scores)
 #endif
+    if constexpr (STAGE3) {
+        constexpr int NPV = PG * DB;                        // fragments of a V^T tile
+        auto mask_init = [&](int kt, f32x4 (&s)[KB][NTQ]) {     // tile kt's padding / causal mask, its sums from zero
+            const bool need = (kt + 1) * KT > w.valid || (a.causal && (kt + 1) * KT > qw0);
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) {
+                if (need) mask_tile(t, kt, s);
+                psum[t] = 0.f;
+            }
+        };
+        auto pv = [&](int kt, u32x4 (&pf)[PG][NTQ], auto filler) {
+            using LV = FragLayout<ROWV, DB>;
+            uint32_t fbv[LV::VAR];
+            LV::bases(lds0 + 2 * TB + (kt & 1) * TB, idx, g, fbv);
+            lds_stream<LV, NPV, 6>(fbv, [&](auto ic, const u32x4& vf) {
+                constexpr int i = decltype(ic)::value;
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) mma_kg<P, i / DB, false, 0>(oacc[i % DB][t], vf, pf, t, oacc[i % DB][t]);
+                filler(ic);
+            });
+        };
+        // a p of the tile just exponentiated past the ceiling (wave-uniform test; the branch is cold)
+        auto settle = [&](f32x4 (&s)[KB][NTQ], f32x4 (&nxt)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
+            bool high = false;
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) high |= psum[t] > (a.rebase_always ? 1.0f : P::kProbCeil);
+            if (__any(high)) rebase(s, nxt, pf);
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) lrun[t] += psum[t];
+        };
+        u32x4 pfa[PG][NTQ], pfb[PG][NTQ];
+        // tile 0's p (under the scores of tile 1, when there is one): the state the loop starts from is
+        // pfa = p of tile 0, scur = the raw scores of tile 1
+        if (ntiles > 0) {
+            if (ntiles > 2) stage_k(2);
+            mask_init(0, scur);
+            if (ntiles > 1) {
+                scores(1, snext, [&](auto ic) { exp_ops.template operator()<decltype(ic)::value, NSTEP>(scur, pfa); });
+            } else {
+                [&]<int... U>(std::integer_sequence<int, U...>) { (exp_half(std::integral_constant<int, U>{}, scur, pfa), ...); }(std::make_integer_sequence<int, NUOP>{});
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int t = 0; t < NTQ; ++t) snext[kb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            settle(scur, snext, pfa);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) scur[kb][t] = snext[kb][t];
+        }
+        // iteration kt: DMA K(kt+3), V(kt+1) | scores(kt+2) and O += V P(kt), the exponentials of tile kt+1 in the gaps of both
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (kt + 3 < ntiles) stage_k(kt + 3);
+            if (kt + 1 < ntiles) stage_v(kt + 1);
+            if (kt + 2 < ntiles) {
+                constexpr int NS = NSTEP + NPV;
+                mask_init(kt + 1, scur);
+                scores(kt + 2, snext, [&](auto ic) { exp_ops.template operator()<decltype(ic)::value, NS>(scur, pfb); });
+                pv(kt, pfa, [&](auto ic) { exp_ops.template operator()<NSTEP + decltype(ic)::value, NS>(scur, pfb); });
+                settle(scur, snext, pfb);
+            } else if (kt + 1 < ntiles) {
+                mask_init(kt + 1, scur);
+                pv(kt, pfa, [&](auto ic) { exp_ops.template operator()<decltype(ic)::value, NPV>(scur, pfb); });
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int t = 0; t < NTQ; ++t) snext[kb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                settle(scur, snext, pfb);
+            } else {
+                pv(kt, pfa, [](auto) {});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) scur[kb][t] = snext[kb][t];
+#pragma unroll
+            for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) pfa[pg][t] = pfb[pg][t];
+        }
+    } else
     // iteration kt: DMA K(kt+2), V(kt+1) | scores(kt+1) with softmax(kt) in its MFMA gaps | O += V P(kt)
     for (int kt = 0; kt < ntiles; ++kt) {
         stamp(kt, 0);
