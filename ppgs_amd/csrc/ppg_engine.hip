@@ -79,7 +79,7 @@ struct Plan {
     PpgPlanInfo info{};
 };
 
-void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads, bool narrow_tiles) {
+void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads, int narrow_tiles) {
     plan->groups.clear();
     const int total = plan->info.tokens;
     size_t w = 0;
@@ -105,7 +105,7 @@ void split_groups(Plan* plan, int ngroups, int qtile, int xcd_heads, bool narrow
         for (const PpgWindow& win : grp.windows) longest = std::max(longest, win.valid);
         for (int wi = 0; wi < (int)grp.windows.size(); ++wi) {
             const PpgWindow& win = grp.windows[wi];
-            const int narrow = narrow_tiles && (2 * win.valid <= longest || win.frames <= qtile / 2);
+            const int narrow = narrow_tiles && (narrow_tiles == 2 || 2 * win.valid <= longest || win.frames <= qtile / 2);
             for (int q0 = 0; q0 < win.frames; q0 += narrow ? qtile / 2 : qtile)
                 grp.items.push_back(AttnItem{wi, q0, win.tok_off, win.vt_off, win.frames, win.valid, narrow, 0});
         }
@@ -276,7 +276,7 @@ struct PpgEngine {
     bool outconv = true;     // output convolution with LDS-resident weights where it applies (ppg_outconv.hip; PPGS_AMD_OUTCONV=0: linear_kernel)
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
-    bool attn_narrow = true; // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width)
+    int attn_narrow = 1;     // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width; 2: half-width tiles for every window)
     bool attn64 = false;     // PPGS_AMD_ATTN64=1: whole-batch attention on ppg_attn64.hip (head dimension 128, 16-bit modes) instead of attn_mixed_kernel
     unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
     int ffn32x2 = 3;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 3 = out-proj + LN1 + FFN + LN2 + the next layer's Q/K/V in ONE feature-split launch per layer (ppg_ffn32x2.hip), 2 = without the Q/K/V tail, 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
@@ -564,7 +564,7 @@ int group_count(const PpgEngine* e, int tokens) {
 int plan_qtile(const PpgEngine* e) { return e->attn64 ? ppg::attn64_query_tile() : ppg::attn_query_tile(e->head_dim); }
 
 size_t finish_plan(const PpgEngine* e, Plan* p) {
-    split_groups(p, group_count(e, p->info.tokens), plan_qtile(e), e->attn_xcd ? e->cfg.heads : 0, e->attn_narrow && e->head_dim == 128 && !e->attn64);
+    split_groups(p, group_count(e, p->info.tokens), plan_qtile(e), e->attn_xcd ? e->cfg.heads : 0, (e->head_dim == 128 && !e->attn64) ? e->attn_narrow : 0);
     size_t off = 0;
     for (PlanGroup& grp : p->groups) {
         grp.ws_offset = off;
@@ -958,7 +958,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
     if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = std::max(0, std::min(atoi(v), 2));
     // (ppg_attn64.hip: built and parity-green, NOT the default -- at 32 x 1000 frames its long workgroups take 25 us
     // against 21 and the 64 short ones a second round of 14 us on a quarter of the chip: DESIGN 4.2, profiles/r5_attn64_*)
     e->attn64 = false;
