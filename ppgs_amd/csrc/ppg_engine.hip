@@ -1140,7 +1140,7 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
             }, &d.wq_img);
             if (rc) return rc;
         }
-        if (e->split && e->ffn32x2 && H == 256 && F % 128 == 0) {
+        if (e->split && e->ffn32x2 && ppg::ffn32x2_supported(H, F)) {      // (an engine outside it -- F > 3328 -- keeps the token-split kernels)
             // ppg_ffn32x2.hip: every A fragment twice, as the fp16 hi plane and the fp16 lo plane of the fp32 weight.
             // W1: [chunk][wave][plane][ks], rows natural, K natural (the panel is loaded in natural order);
             // W2: [chunk][wave][plane][rb][ks8], rows in the order phi, K = the chunk's h in accumulator order

@@ -519,11 +519,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 namespace ppg {
 
 int ffn32x2_tokens() { return XTOK; }
+// the geometries launch_ffn32x2 takes (its own checks: hidden 256, whole chunks, b1 behind the fixed LDS map)
+bool ffn32x2_supported(int H, int F) { return H == XH && F >= HC && F % HC == 0 && F <= 8192 && (size_t)X_B1 + (size_t)F * 4 <= 163840; }
 
 hipError_t launch_ffn32x2(const Ffn32X2Args& a, hipStream_t s) {
-    if (a.H != XH || a.F % HC || a.F < HC || a.F > 8192 || a.M <= 0) return hipErrorInvalidValue;
+    if (!ffn32x2_supported(a.H, a.F) || a.M <= 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)X_B1 + (size_t)a.F * 4;
-    if (lds > 163840) return hipErrorInvalidValue;
     static ppg::LdsLimit limit[3];
     const bool op = a.wo_img != nullptr, qkv = a.wq_img != nullptr;
     if (qkv && !op) return hipErrorInvalidValue;            // (the tail comes with the fused out-projection only)

@@ -33,6 +33,7 @@ hipError_t launch_gemm32(int precision, const Gemm32Args& a, hipStream_t s);
 hipError_t launch_posconv(int precision, const PosConvArgs& a, int batch, hipStream_t s);
 hipError_t launch_ffn32x2(const Ffn32X2Args& a, hipStream_t s);
 int ffn32x2_tokens();
+bool ffn32x2_supported(int H, int F);     // what launch_ffn32x2 accepts: the engine builds the hi + lo images and dispatches on it
 // output convolution + mask + softmax with the weights resident in LDS (ppg_outconv.hip): 16-bit precisions, hidden 256, whole batches
 bool outconv_supported(int precision, const LinearArgs& a);
 hipError_t launch_outconv(int precision, const LinearArgs& a, hipStream_t s);

@@ -2,7 +2,7 @@
 # wav2vec2 body (16 x 499 frames, bf16) under rocprofv3 --kernel-trace, summarised per (kernel, grid) by
 # tools/trace_by_grid.py -- gemm32_kernel runs three GEMM shapes per layer, which --stats would average together.
 # usage: tests/prof_body.sh <tag>      -> gpurun_out/prof_<tag>_body/by_grid_{one,two}_pipelines.txt
-tag=${1:-r4}
+tag=${1:-r5}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for n in 1 2; do

@@ -3,7 +3,7 @@
 #   c3: tools/bench_c3.py (w2v2fb: feature encoder + wav2vec2 body + hidden-512 PPG network)
 #   c5: tools/bench_streaming.py (causal 64 x 160-frame chunks) and the batched KV-cached stream step
 # usage: tests/prof_configs.sh <tag>      -> gpurun_out/prof_<tag>_{c3,c5,c5stream}/
-tag=${1:-r4}
+tag=${1:-r5}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for cfg in c3 c5 c5stream; do

@@ -1,7 +1,7 @@
 # One gpurun call that produces every record of a round under gpurun_out/final_<tag>/ (copy what is to be judged
-# into profiles/):   bash tools/final_records.sh r4
+# into profiles/):   bash tools/final_records.sh r5
 set -x
-tag=${1:-r4}
+tag=${1:-r5}
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/final_$tag
 mkdir -p $out
@@ -36,6 +36,7 @@ for c in c3 c5 c5stream; do cp gpurun_out/prof_${tag}_$c/kernel_stats.csv $out/$
 timeout 600 bash tests/prof_body.sh $tag > $out/prof_body.log 2>&1
 for n in one two; do cp gpurun_out/prof_${tag}_body/by_grid_${n}_pipelines.txt $out/${tag}_body_by_grid_${n}_pipelines.txt; done
 timeout 600 python tools/bench_c3.py > $out/c3.log 2>&1; grep "^{" $out/c3.log | tail -1 > $out/${tag}_bench_c3.json
+timeout 600 python tools/bench_c3.py fp16x2 > $out/c3_x2.log 2>&1; grep "^{" $out/c3_x2.log | tail -1 > $out/${tag}_bench_c3_fp16x2.json
 PPGS_BENCH_FORCE_DIST=1 timeout 600 python bench.py --workload c4 > $out/c4.log 2>&1; grep "^{" $out/c4.log | tail -1 > $out/${tag}_bench_c4.json
 timeout 300 python tools/bench_streaming.py > $out/c5.log 2>&1; grep "^{" $out/c5.log | tail -1 > $out/${tag}_bench_c5.json
 # the N-rank host path on the one GPU present (gloo; NOT a multi-GPU measurement): 8 launch loops through one GPU's queues
@@ -43,3 +44,5 @@ PPGS_BENCH_ALIAS_GPUS=1 timeout 600 python bench.py --gpus 8 --steps 20 --warmup
 timeout 120 python tools/time_frontend.py > $out/time_frontend.txt 2>&1
 timeout 200 python tools/two_stream_steps.py --streams 1 2 --steps 400 > $out/two_stream_steps.txt 2>&1
 ls -la $out
+# (the merge back takes <= 64 MiB: the traces stay on the box)
+rm -rf gpurun_out/prof_${tag} gpurun_out/prof_${tag}_*
