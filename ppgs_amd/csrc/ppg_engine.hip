@@ -1569,6 +1569,7 @@ struct PpgStream {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool graph_steps = false;     // (measured: a replay costs MORE than the launches it replaces, profiles/r5_stream_step_graph.txt)
+    int fused_layers = 1;         // PPGS_AMD_STREAM_FUSED: 1 = one fused launch per layer for steps of >= 512 row blocks, 0 never, 2 always
     ~PpgStream() {
         if (e) (void)hipSetDevice(e->device);
         for (auto& kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -1594,6 +1595,7 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     std::unique_ptr<PpgStream> st(new PpgStream);
     st->e = e; st->batch = batch; st->cap = max_frames; st->rows = round_up(max_frames, 32); st->dtype = feature_dtype;
     if (const char* v = getenv("PPGS_AMD_STREAM_GRAPH")) st->graph_steps = atoi(v) != 0;
+    if (const char* v = getenv("PPGS_AMD_STREAM_FUSED")) st->fused_layers = std::max(0, std::min(atoi(v), 2));
     st->received.assign(batch, 0); st->x_valid.assign(batch, 0); st->o_valid.assign(batch, 0); st->finished.assign(batch, 0);
     const PpgConfig& c = e->cfg;
     const int R = st->rows, MT = batch * R;
@@ -1763,7 +1765,7 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
             for (auto& kv : st->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
             st->graphs.clear();
         }
-        sg = &st->graphs[std::array<int, 6>{nmap[0], nmap[1], nmap[2], nitems, softmax, max_count > 0}];
+        sg = &st->graphs[std::array<int, 6>{nmap[0], nmap[1], nmap[2], nitems, softmax, max_count > 0}];       // (the fused-layer choice follows nmap[0])
         HIP_OK(hipEventRecord(st->ev_fork, caller));
         HIP_OK(hipStreamWaitEvent(st->gstream, st->ev_fork, 0));
         s = st->gstream;
@@ -1868,11 +1870,18 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
             if (st->d_tickets) cap = std::min(cap, e->ffn_split_max > 0 ? 8 : 4);
             while (ffn_splits * 2 <= cap && wgs * ffn_splits * 2 <= e->num_cus) ffn_splits *= 2;
         }
+        // One launch per layer besides attention for BIG steps (round 5): out-projection + LayerNorm-1 + FFN + LayerNorm-2
+        // + the NEXT layer's Q/K/V in the token-split fused kernel the one-shot forward uses for small batches, here under
+        // the step's row map.  Its workgroups stream a whole layer's weights each (no hidden splits: a split would redo
+        // the out-projection) -- ~85 us per layer however few they are, so only a step of >= 512 row blocks gains
+        // (64 streams x 160 frames: 725 -> 639 us; 64 x 16: 363 -> 491 us, one stream 274 -> 432 us: four launches stay).
+        // PPGS_AMD_STREAM_FUSED=0: never, 2: always (the stream tests run green either way).
+        const bool fused = (st->fused_layers == 2 || (st->fused_layers == 1 && nmap[0] >= 512)) && e->ffn_fused && e->op_fused && e->qkv_fused && !e->split;
         for (int l = 0; l < c.num_layers; ++l) {
             const DevLayer& d = e->layers[l];
             char* qk = qk_of(l);
             char* vt = vt_of(l);
-            {
+            if (!fused || l == 0) {
                 LinearArgs a = base_args();
                 a.act = act_x; a.lda_bytes = H * e->sz;
                 a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
@@ -1886,6 +1895,22 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
                 a.ao = ao; a.H = H; a.causal = 1;
                 a.items = d_items; a.win = d_win; a.M = MT; a.ao_tiled = 0; a.heads = c.heads;
                 LAUNCH_OK(ppg::launch_attn(prec, a, nitems, c.heads, e->head_dim, s), "stream attention");
+            }
+            if (fused) {
+                FfnArgs a{};
+                a.X = X; a.Xb = Xb;
+                a.W1 = d.w1k; a.b1 = d.b1; a.W2p = d.w2p; a.b2 = d.b2;
+                a.gamma = d.g2; a.beta = d.e2; a.H = H; a.F = F; a.M = MT;
+                a.splits = 1; a.partial = nullptr;
+                a.rowmap = reinterpret_cast<const int*>(st->d_tables + map_off[0]); a.map_blocks = nmap[0];
+                a.ao = ao; a.Wo = d.wo; a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1;
+                if (l + 1 < c.num_layers) {
+                    const DevLayer& nx = e->layers[l + 1];
+                    a.Wq = nx.wqkvk; a.bq = nx.bqkv; a.qk_out = qk_of(l + 1); a.vt_out = vt_of(l + 1); a.vt_ld = ws.vt_ld;
+                    a.blk_win = st->d_blk; a.win = d_win;
+                }
+                LAUNCH_OK(ppg::launch_ffn(prec, a, 1, s), "stream fused layer");
+                continue;
             }
             {
                 LinearArgs a = base_args();
