@@ -46,7 +46,8 @@ enum {
                                reference's fp32 forward -- the autocast-off route of ppgs/core.py:586-594)
                                at a third of the fp16 MFMA rate, 5x the f32-input MFMA rate.  Hidden 256 with
                                head dimension 128 (mel-sized models) and hidden 512 with head dimension 256
-                               (the w2v2fb network; no KV-cached stream there); magnitudes below 65504 as fp16   */
+                               (the w2v2fb network; no KV-cached stream there); the wav2vec2 engines
+                               (ppg_w2v2_create / ppg_w2v2_body_create) take it too; magnitudes below 65504 as fp16   */
 };
 
 /* dtype tags for feature tensors handed to ppg_encode */
@@ -337,7 +338,8 @@ int ppg_stream_push_batch(PpgStream* stream, const void* chunk_device, int n_max
  *   audio   : device fp32 (batch, samples), already padded as the caller wants
  *   out     : device fp32 (batch, ppg_w2v2_frames(samples), 512) = HF's
  *             extract_features before the feature projection
- * The layers run as MFMA GEMMs in the precision given at creation.
+ * The layers run as MFMA GEMMs in the precision given at creation (any PPG_PRECISION_*; FP16X2: layers 1..6 on fp16
+ * hi + lo operand pairs, <= 1e-4 against HF's fp32 output).
  */
 typedef struct PpgW2v2Weights {
     const float* conv_weight[7];
