@@ -353,7 +353,7 @@ def test_hot_kernels_do_not_wait_for_store_acknowledgements():
     kernels = wait_scan.scan(library)
     budget = {
         'layer32_kernel<PrecBF16, 256, true, 5>': 4, 'layer32_kernel<PrecBF16, 256, false, 5>': 0,
-        'head32_kernel<PrecBF16, 5>': 13, 'attn_mixed_kernel<PrecBF16>': 2, 'outconv_kernel<PrecBF16>': 0,
+        'head32_kernel<PrecBF16, 5>': 13, 'attn_mixed_kernel<PrecBF16>': 3, 'outconv_kernel<PrecBF16>': 0,     # (attention: the tile loops' own end-of-iteration waits: two-stage, three-stage and its tile-0 stage)
         'gemm32_kernel<PrecBF16, 4, 0>': 0, 'gemm32_kernel<PrecBF16, 4, 1>': 0, 'gemm32_kernel<PrecBF16, 5, 3>': 0,
         'posconv_kernel<PrecBF16>': 0, 'w2v2_layernorm_kernel<PrecBF16, 768>': 0,
         'linear_kernel<PrecBF16, 1, 16, 1>': 1, 'ffn32x2_kernel<true, true>': 3,
