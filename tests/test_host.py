@@ -293,8 +293,8 @@ def test_w2v2fb_engine_cache_is_bound_to_the_model_object(monkeypatch):
     assert w2v2fb.feature_encoder_for(device, a) is ea and w2v2fb.body_for(device, a) is ba and len(built) == 2
     # an entry under b's key that belongs to another model (what id reuse produces) is not handed out
     from ppgs_amd import core
-    w2v2fb._encoders[(str(device), id(b), core.PRECISION)] = w2v2fb._encoders[(str(device), id(a), core.PRECISION)]
-    w2v2fb._bodies[(str(device), id(b), core.PRECISION)] = w2v2fb._bodies[(str(device), id(a), core.PRECISION)]
+    w2v2fb._encoders[(str(device), id(b), w2v2fb.w2v2_precision())] = w2v2fb._encoders[(str(device), id(a), w2v2fb.w2v2_precision())]
+    w2v2fb._bodies[(str(device), id(b), w2v2fb.w2v2_precision())] = w2v2fb._bodies[(str(device), id(a), w2v2fb.w2v2_precision())]
     assert w2v2fb.feature_encoder_for(device, b) is not ea and w2v2fb.body_for(device, b) is not ba and len(built) == 4
     # and the cache holds the models
     assert any(entry[0] is a for entry in w2v2fb._encoders.values())
