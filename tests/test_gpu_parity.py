@@ -1477,12 +1477,16 @@ def test_c4_thousand_utterances_slice():
             assert err < FP32_TOL, (index, err)
 
 
+@pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('precision', ['fp32', 'fp16'])
-def test_batched_kv_cached_streams_equal_causal_forward(precision):
+def test_batched_kv_cached_streams_equal_causal_forward(precision, fused, monkeypatch):
     """Several utterances advanced together by ONE launch sequence per step (engine.batched_stream: row-mapped
     launches of the token-split kernels, one attention launch over all items' query tiles): every item equals
     the oracle's causal forward of its own utterance, with ragged, unaligned pushes per item, items that sit
-    steps out, items that end at different steps and an item of one frame."""
+    steps out, items that end at different steps and an item of one frame.  `fused`: every step's layers as ONE
+    fused launch each (out-projection + LayerNorm-1 + FFN + LayerNorm-2 + the next layer's Q/K/V under the row map --
+    what steps of >= 512 row blocks take by default, PPGS_AMD_STREAM_FUSED=2 forces it) or as four launches (=0)."""
+    monkeypatch.setenv('PPGS_AMD_STREAM_FUSED', '2' if fused else '0')
     engine, state = eng(precision=precision, causal=True)
     gen = torch.Generator().manual_seed(91)
     totals = [437, 160, 1, 500, 33, 275, 96]
