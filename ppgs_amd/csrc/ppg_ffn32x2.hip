@@ -265,9 +265,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stream<OffA1, 16 * 6, 6>(pb0, pb1, [&](auto ic, const u32x4& bf) {
             constexpr int i = decltype(ic)::value;
             constexpr int ks = i / 6, tb = i % 3;
-            if constexpr (i < 3) hacc[tb] = P::mma32(s1[0], bf, bias);
-            else hacc[tb] = P::mma32(s1[ks], bf, hacc[tb]);
+            // (h in architectural registers -- inline-asm MFMAs, as ppg_layer32.hip's phase A: its consumers are VALU
+            // instructions, and the builtin's accumulation registers cost them one v_accvgpr_read per value)
+            if constexpr (i < 3) P::mma32v0(hacc[tb], s1[0], bf, bias);
+            else P::mma32v(hacc[tb], s1[ks], bf);
             if constexpr (i % 6 == 1) gload_frag<16 + i / 6>(s2[i / 6], voff, w1c);
+            if constexpr (i == 16 * 6 - 1) asm volatile("" :: "v"(bias));        // (b1 stays b1's until its last reader is done)
         });
         cstamp(1);
         vm_wait_all(s2);
@@ -277,10 +280,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int i = decltype(ic)::value;
             constexpr int ks = i / 3, tb = i % 3;
             if constexpr (i == 0) __builtin_amdgcn_s_barrier();        // every wave has read the previous chunk's h
-            hacc[tb] = P::mma32(s2[ks], bf, hacc[tb]);
+            P::mma32v(hacc[tb], s2[ks], bf);
             if constexpr (i % 3 == 1) gload_frag<i / 3>(s1[i / 3], voff, w2c);
         });
         cstamp(7);
+        // (the compiler inserts no wait states behind an asm MFMA: block 0's accumulators were last written three MFMAs
+        // ago, the others are read a unit or two of VALU work later; the nops cover the pipe's drain)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         // h = relu(hacc), split: registers 8 s2 .. + 7 of block t are K-step 2 wave + s2 of the chunk's h
 #pragma unroll
         for (int t = 0; t < XTB; ++t)
@@ -422,16 +428,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (m >= a.M) return;
                 const float y[16] = {c[0] + b4[rb][0].x, c[1] + b4[rb][0].y, c[2] + b4[rb][0].z, c[3] + b4[rb][0].w, c[4] + b4[rb][1].x, c[5] + b4[rb][1].y, c[6] + b4[rb][1].z, c[7] + b4[rb][1].w,
                                      c[8] + b4[rb][2].x, c[9] + b4[rb][2].y, c[10] + b4[rb][2].z, c[11] + b4[rb][2].w, c[12] + b4[rb][3].x, c[13] + b4[rb][3].y, c[14] + b4[rb][3].z, c[15] + b4[rb][3].w};
-                char* dst = a.qk_out + (size_t)m * (2 * XH * 4) + KIND * (XH * 4) + (2 * wave + rb) * 128 + hh * 32;
+                u32x4 fh[2], fl[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    u32x4 fh, fl;
-                    uint32_t* ph = reinterpret_cast<uint32_t*>(&fh);
-                    uint32_t* pl = reinterpret_cast<uint32_t*>(&fl);
+                    uint32_t* ph = reinterpret_cast<uint32_t*>(&fh[s]);
+                    uint32_t* pl = reinterpret_cast<uint32_t*>(&fl[s]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) PrecX2::split2(y[8 * s + 2 * j], y[8 * s + 2 * j + 1], ph[j], pl[j]);
-                    *reinterpret_cast<u32x4*>(dst + 16 * s) = fh;
-                    *reinterpret_cast<u32x4*>(dst + 64 + 16 * s) = fl;
+                }
+                if (regular) {
+                    // (as ppg_layer32.h's tail: the two 16-byte halves of a plane traded across 16-lane rows, one
+                    // v_permlane16_swap per dword -- an instruction writes 16 rows x 64 contiguous bytes of a plane
+                    // instead of 32 rows x 2 pieces)
+                    const int r16 = lane & 15, k16 = lane >> 4;
+                    char* d16 = a.qk_out + (size_t)(m0 + 32 * t + r16) * (2 * XH * 4) + KIND * (XH * 4) + (2 * wave + rb) * 128 + 16 * k16;
+#pragma unroll
+                    for (int plane = 0; plane < 2; ++plane) {
+                        u32x4 lo, hi;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const auto sw = plane ? __builtin_amdgcn_permlane16_swap(fl[0][d], fl[1][d], false, false)
+                                                  : __builtin_amdgcn_permlane16_swap(fh[0][d], fh[1][d], false, false);
+                            lo[d] = sw[0]; hi[d] = sw[1];
+                        }
+                        *reinterpret_cast<u32x4*>(d16 + 64 * plane) = lo;
+                        *reinterpret_cast<u32x4*>(d16 + 64 * plane + (size_t)16 * (2 * XH * 4)) = hi;
+                    }
+                } else {
+                    char* dst = a.qk_out + (size_t)m * (2 * XH * 4) + KIND * (XH * 4) + (2 * wave + rb) * 128 + hh * 32;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        *reinterpret_cast<u32x4*>(dst + 16 * s) = fh[s];
+                        *reinterpret_cast<u32x4*>(dst + 64 + 16 * s) = fl[s];
+                    }
                 }
             } else {
                 // lane = V^T row fbase + 32 rb + tok, registers 4 q + r = token 8 q + 4 hh + r of the block
