@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto load16 = [&](u32x4 (&wf)[16], const char* base) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
     };
+    const char* wimg = a.win_img + ((size_t)wave * RB * KSI) * 1024;
+    const char* wq0 = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
+#ifndef PPG_HEAD_W_OLD
+    // the convolution's first-round weight fragments travel under the gather (nothing below touches the two register
+    // sets before the round's wait: tools/asm_load_scan.py checks the built code)
+    load16(w1f, wimg);
+    load16(w2f, wimg + (size_t)KSI * 1024);
+#endif
 
     // ---- 1. gather: thread r < TOKS + 2 HALO takes row r = token m0 - HALO + r, all channels (for one channel,
     // neighbouring threads read neighbouring frames)
@@ -161,7 +169,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x16 yacc[RB][TB];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const uint32_t rb0 = lds0 + G::L_H + (uint32_t)(tok * ROWB + hh * 16);
-    const char* wimg = a.win_img + ((size_t)wave * RB * KSI) * 1024;
     // PE rows of the lane's tokens, features f0 .. f0 + 15 of row block rb: fetched a phase ahead of their use
     float4 pe[TB][4];
     auto load_pe = [&](int rb) {
@@ -174,8 +181,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto round = [&](auto r_tag, auto after_wait) {
         constexpr int R = decltype(r_tag)::value;
         // (16 fragments are fetched where KSH = 15 are used: the image carries one pad fragment at its end)
+#ifdef PPG_HEAD_W_OLD
         load16(w1f, wimg + (size_t)(KSH * R) * 1024);
         load16(w2f, wimg + (size_t)(KSI + KSH * R) * 1024);
+#endif
         vm_wait_all(w1f);
         vm_wait_all(w2f);
         after_wait();
@@ -197,6 +206,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 yacc[0][tb] = P::mma32(w1f[ksl], b, yacc[0][tb]);
                 yacc[1][tb] = P::mma32(w2f[ksl], b, yacc[1][tb]);
             }
+#ifndef PPG_HEAD_W_OLD
+            // the second round's fragment ksl is requested behind the first round's last use of its registers
+            if constexpr (R == 0 && tb == TB - 1) {
+                gload_frag<ksl>(w1f[ksl], voff, wimg + (size_t)KSH * 1024);
+                gload_frag<ksl>(w2f[ksl], voff, wimg + (size_t)(KSI + KSH) * 1024);
+            }
+#endif
         });
     };
     if (!(PPG_DBG(a) & 1)) round(std::integral_constant<int, 0>{}, [] {});
@@ -245,9 +261,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     emit(std::integral_constant<int, 0>{});
     emit(std::integral_constant<int, 1>{});
     pstamp(5);
-    // layer 0's W_qkv fragments of the tail's first half-step (not earlier: the compiler may move registers an asm
-    // load has not landed in yet, and the epilogue above is its code)
-    load16(w1f, a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024);
+    // layer 0's W_qkv fragments of the tail's first half-step (not earlier: requested during the second round, hipcc
+    // copies the registers into the accumulation file inside the epilogue above -- its code -- before the loads have
+    // landed, and hands them to the LDS ring: tools/asm_load_scan.py shows it)
+    load16(w1f, wq0);
     vm_wait_all(w1f);
     pstamp(6);
 

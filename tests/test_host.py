@@ -363,6 +363,26 @@ def test_hot_kernels_do_not_wait_for_store_acknowledgements():
         assert kernels[name]['vmcnt0_after_store'] <= allowed, (name, dict(kernels[name]))
 
 
+def test_head_kernel_leaves_its_in_flight_weight_registers_alone():
+    """The head kernel requests its convolution weights with inline-asm loads at its top and awaits them by hand behind
+    the gather -- code the compiler places, blind to the loads.  tools/asm_load_scan.py follows every hand-placed
+    fragment load of the built head kernels in issue order and fails on an instruction that names a register still in
+    flight (hipcc did exactly that when the tail's weights were requested ahead of the epilogue: the registers were
+    copied into the accumulation file before the loads had landed)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    library = os.path.join(root, 'ppgs_amd', 'libppgs_amd.so')
+    if not os.path.exists(library) or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no built library / llvm-objdump')
+    spec = importlib.util.spec_from_file_location('asm_load_scan', os.path.join(root, 'tools', 'asm_load_scan.py'))
+    asm_load_scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(asm_load_scan)
+    seen, tracked, bad = asm_load_scan.scan(library, 'head32_kernel')
+    assert seen == 4 and tracked >= 4 * 100, (seen, tracked)
+    assert not bad, bad[:5]
+
+
 def test_bench_refuses_experiment_switches_and_reads_the_clock_probe(monkeypatch, tmp_path):
     """bench.py's line is self-defending: with a PPGS_AMD_* experiment switch in the environment it
     exits before touching the GPU (--allow-ablation: the switches are carried in the line, its `value` nulled);
