@@ -1478,6 +1478,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 
     // Q fragments
     u32x4 qf[DG][NTQ];
+#ifdef PPG_ATTN_WAIT_ALL
 #pragma unroll
     for (int t = 0; t < NTQ; ++t) {
         const int tq = qw0 + 16 * t + idx;
@@ -1490,6 +1491,21 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             qf[kg][t] = v;
         }
     }
+#else
+    // requested by hand (the compiler, blind to the tile DMAs issued behind them, would wait for its own loads with
+    // vmcnt(0) -- for every tile of the prologue -- at the first score MFMA): unconditional, a block past the window's
+    // padded rows reads the window's first row and is zeroed behind the wait
+    bool q_ok[NTQ];
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+        q_ok[t] = (qw0 + 16 * t) < ((w.frames + 15) & ~15);
+        const int m = w.tok_off + (q_ok[t] ? qw0 + 16 * t + idx : 0);
+        const char* src = a.qk + (size_t)m * a.qk_ld_bytes + (size_t)head * ROWK + g * 16;
+#pragma unroll
+        for (int kg = 0; kg < DG; ++kg)
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[kg][t]) : "v"(src), "n"(kg * 64) : "memory");
+    }
+#endif
 
     int kend = w.valid;                              // keys >= valid are masked
     if (a.causal) kend = min(kend, item.q0 + NW * 16 * NTQ);
@@ -1665,7 +1681,27 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 
     if (ntiles > 0) { stage_k(0); stage_v(0); }
     if (ntiles > 1) stage_k(1);
+#ifdef PPG_ATTN_WAIT_ALL
     dma_wait_barrier();
+#else
+    // the first scores need the Q rows and K tile 0 only: V^T tile 0 and K tile 1 (the younger requests: vector-memory
+    // operations complete in issue order) travel on under them
+    {
+        constexpr int OPS = TB / 1024 / NW;                 // DMA instructions of a tile per wave
+        static_assert(2 * OPS < 64, "vmcnt range");
+        if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * OPS) : "memory");
+        else if (ntiles > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+            for (int kg = 0; kg < DG; ++kg) {
+                asm volatile("" : "+v"(qf[kg][t]));
+                if (!q_ok[t]) qf[kg][t] = u32x4{0u, 0u, 0u, 0u};
+            }
+        __syncthreads();
+    }
+#endif
 
     f32x4 scur[KB][NTQ], snext[KB][NTQ];
     if (ntiles > 0) {
@@ -1685,6 +1721,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             }
         }
     }
+#ifndef PPG_ATTN_WAIT_ALL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // V^T tile 0, K tile 1
+#endif
     __syncthreads();                       // K buffer 0 is re-filled by iteration 0's DMA
 
 #ifdef PPG_ATTN_TIMING

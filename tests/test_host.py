@@ -363,7 +363,7 @@ def test_hot_kernels_do_not_wait_for_store_acknowledgements():
         assert kernels[name]['vmcnt0_after_store'] <= allowed, (name, dict(kernels[name]))
 
 
-def test_head_kernel_leaves_its_in_flight_weight_registers_alone():
+def test_hand_placed_loads_stay_untouched_until_their_wait():
     """The head kernel requests its convolution weights with inline-asm loads at its top and awaits them by hand behind
     the gather -- code the compiler places, blind to the loads.  tools/asm_load_scan.py follows every hand-placed
     fragment load of the built head kernels in issue order and fails on an instruction that names a register still in
@@ -381,6 +381,11 @@ def test_head_kernel_leaves_its_in_flight_weight_registers_alone():
     seen, tracked, bad = asm_load_scan.scan(library, 'head32_kernel')
     assert seen == 4 and tracked >= 4 * 100, (seen, tracked)
     assert not bad, bad[:5]
+    # the attention kernels request their Q rows the same way (awaited with a counted vmcnt beside the tile DMAs)
+    for family, kernels in (('attn_mixed_kernel', 4), ('attn_kernel', 8)):
+        seen, tracked, bad = asm_load_scan.scan(library, family)
+        assert seen == kernels and tracked >= 4 * kernels, (family, seen, tracked)
+        assert not bad, (family, bad[:5])
 
 
 def test_bench_refuses_experiment_switches_and_reads_the_clock_probe(monkeypatch, tmp_path):

@@ -18,7 +18,7 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = '/opt/rocm/lib/llvm/bin'
-LOAD = re.compile(r'^\s*global_load_dwordx4\s+([va])\[(\d+):(\d+)\],\s*v\d+,\s*s\[\d+:\d+\]')
+LOAD = re.compile(r'^\s*global_load_dwordx4\s+([va])\[(\d+):(\d+)\],\s*(?:v\d+,\s*s\[\d+:\d+\]|v\[\d+:\d+\],\s*off)')
 REG = re.compile(r'\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]')
 
 
