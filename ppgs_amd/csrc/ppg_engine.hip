@@ -277,12 +277,12 @@ struct PpgEngine {
     bool head32 = true;      // gather + input convolution + layer 0's Q/K/V in one kernel where it applies (with layer32, hidden 256, <= 96 input channels; PPGS_AMD_HEAD32=0: three launches)
     char* win_img = nullptr; // the input convolution as fragment images (ppg_head32.hip)
     int attn_narrow = 1;     // half-width query tiles for the short windows of a batch (PPGS_AMD_ATTN_NARROW=0: one width; 2: half-width tiles for every window)
-    bool attn64 = false;     // PPGS_AMD_ATTN64=1: whole-batch attention on ppg_attn64.hip (head dimension 128, 16-bit modes) instead of attn_mixed_kernel
     unsigned* d_overflow = nullptr;   // sticky device flag: a launch produced a non-finite logit for a valid frame (ppg_engine_nonfinite)
     int ffn32x2 = 3;         // fp16x2 mode, hidden 256, batches of >= half a chip of 96-token tiles: 3 = out-proj + LN1 + FFN + LN2 + the next layer's Q/K/V in ONE feature-split launch per layer (ppg_ffn32x2.hip), 2 = without the Q/K/V tail, 1 = the FFN block only, 0 = the token-split kernels always (PPGS_AMD_FFN32X2)
     bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
     bool subtile = true;     // layer32 path, hidden 256: workgroups of two token blocks (three per 160-token tile) when whole tiles would leave two thirds of the CUs idle (PPGS_AMD_SUBTILE=0: whole tiles always)
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
+    bool q_in_attn = false;  // layer32 path, fp16 residual stream (x16), whole tiles: the attention workgroups compute their Q rows themselves (AttnArgs::xq), the layer kernels' tails K | V only
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 2;    // pipelines (HIP streams) a batch of >= 128 x CUs token rows is split into (PPGS_AMD_STREAMS;
@@ -379,7 +379,7 @@ struct PpgEngine {
                     }
             {   // per-workgroup records: start, end, valid keys, HW_ID -> PPGS_AMD_ATTN_TIMING_OUT (tools/attn_timeline.py)
                 std::vector<unsigned long long> rec(4096 * 4);
-                const char* path = getenv("PPGS_AMD_ATTN_TIMING_OUT");
+                const char* path = getenv("PPGS_AMD_ATTN_TIMING_OUT");   // (PPG_ATTN_TIMING builds only: attn_dbg is null otherwise)
                 if (path && hipMemcpy(rec.data(), attn_dbg + 64, rec.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                     FILE* f = fopen(path, "wb");
                     if (f) { fwrite(rec.data(), 8, rec.size(), f); fclose(f); }
@@ -391,7 +391,7 @@ struct PpgEngine {
             const size_t n = 16 * 8192;
             std::vector<unsigned long long> h(n);
             (void)hipDeviceSynchronize();
-            const char* path = getenv("PPGS_AMD_LIN_TIMING_OUT");
+            const char* path = getenv("PPGS_AMD_LIN_TIMING_OUT");   // (PPG_LIN_TIMING builds only)
             FILE* f = fopen(path ? path : "/tmp/lin_timing.bin", "wb");
             if (f && hipMemcpy(h.data(), lin_dbg, n * 8, hipMemcpyDeviceToHost) == hipSuccess) fwrite(h.data(), 8, n, f);
             if (f) fclose(f);
@@ -561,10 +561,10 @@ int group_count(const PpgEngine* e, int tokens) {
 }
 
 // Queries per attention workgroup of the encoder's whole-batch launches
-int plan_qtile(const PpgEngine* e) { return e->attn64 ? ppg::attn64_query_tile() : ppg::attn_query_tile(e->head_dim); }
+int plan_qtile(const PpgEngine* e) { return ppg::attn_query_tile(e->head_dim); }
 
 size_t finish_plan(const PpgEngine* e, Plan* p) {
-    split_groups(p, group_count(e, p->info.tokens), plan_qtile(e), e->attn_xcd ? e->cfg.heads : 0, (e->head_dim == 128 && !e->attn64) ? e->attn_narrow : 0);
+    split_groups(p, group_count(e, p->info.tokens), plan_qtile(e), e->attn_xcd ? e->cfg.heads : 0, e->head_dim == 128 ? e->attn_narrow : 0);
     size_t off = 0;
     for (PlanGroup& grp : p->groups) {
         grp.ws_offset = off;
@@ -864,10 +864,12 @@ int frontend_for(int device, Frontend** out) {
         if ((rc = up(img.data(), img.size() * 2, (const void**)&f.tb.mel_img))) return rc;
         if ((rc = up(prog.data(), prog.size() * 4, (const void**)&f.tb.mel_prog))) return rc;
         f.tb.dbg = nullptr;
-        if (getenv("PPGS_AMD_FE_TIMING") || getenv("PPGS_AMD_FE_CHECK")) {
+#ifdef PPG_FE_TIMING
+        if (getenv("PPGS_AMD_FE_TIMING")) {
             std::vector<unsigned long long> zeros(64, 0);
             if ((rc = up(zeros.data(), 512, (const void**)&f.tb.dbg))) return rc;
         }
+#endif
         f.ready = true;
     }
     *out = &f;
@@ -933,15 +935,17 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     e->in_total_groups = round_up(5 * e->in_groups_per_tap, 2);
     e->out_groups_per_tap = H / e->KG;
     e->out_total_groups = round_up(5 * e->out_groups_per_tap, 2);
-    if (const char* s = getenv("PPGS_AMD_FFN_NT")) e->ffn_nt = atoi(s);
-    if (const char* s = getenv("PPGS_AMD_LIN_NT")) e->lin_nt = atoi(s);
-    if (const char* s = getenv("PPGS_AMD_FFN_UNFUSED")) e->ffn_fused = atoi(s) == 0;
-    if (const char* s = getenv("PPGS_AMD_FFN_SPLIT")) e->ffn_split = atoi(s) != 0;
-    if (const char* s = getenv("PPGS_AMD_FFN32X2")) e->ffn32x2 = atoi(s);
-    if (const char* s = getenv("PPGS_AMD_STREAMS")) e->num_streams = std::max(1, std::min(atoi(s), 4));
-    if (const char* s = getenv("PPGS_AMD_STREAM_ONE_PASS")) e->stream_one_pass = atoi(s) != 0;
-    if (const char* s = getenv("PPGS_AMD_STREAMS_MIN_ROWS")) e->stream_min_rows = std::max(1, atoi(s));
-    if (const char* s = getenv("PPGS_AMD_STREAM_OFFSET_US")) e->stream_offset_us = std::max(0, atoi(s));
+    using ppg::env_switch;
+    using ppg::env_experiment;
+    e->ffn_nt = env_experiment("PPGS_AMD_FFN_NT", e->ffn_nt);
+    e->lin_nt = env_experiment("PPGS_AMD_LIN_NT", e->lin_nt);
+    e->ffn_fused = env_switch("PPGS_AMD_FFN_UNFUSED", !e->ffn_fused) == 0;
+    e->ffn_split = env_experiment("PPGS_AMD_FFN_SPLIT", e->ffn_split) != 0;
+    e->ffn32x2 = env_switch("PPGS_AMD_FFN32X2", e->ffn32x2);
+    e->num_streams = std::max(1, std::min(env_switch("PPGS_AMD_STREAMS", e->num_streams), 4));
+    e->stream_one_pass = env_experiment("PPGS_AMD_STREAM_ONE_PASS", e->stream_one_pass) != 0;
+    e->stream_min_rows = std::max(1, env_experiment("PPGS_AMD_STREAMS_MIN_ROWS", e->stream_min_rows));
+    e->stream_offset_us = std::max(0, env_experiment("PPGS_AMD_STREAM_OFFSET_US", e->stream_offset_us));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     for (int i = 1; i < e->num_streams; ++i) {
         hipStream_t st;
@@ -951,29 +955,24 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
         e->side_streams.push_back(st);
         e->ev_join.push_back(ev);
     }
-    if (const char* v = getenv("PPGS_AMD_OP_FUSED")) e->op_fused = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_FFN_MIXED")) e->ffn_mixed = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_FFN_SPLIT_MAX")) e->ffn_split_max = atoi(v);
-    if (const char* v = getenv("PPGS_AMD_FFN_SPLITS")) e->ffn_splits_forced = atoi(v);
-    if (const char* v = getenv("PPGS_AMD_QKV_FUSED")) e->qkv_fused = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_LAYER32")) e->layer32 = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_ATTN_XCD")) e->attn_xcd = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_ATTN_NARROW")) e->attn_narrow = std::max(0, std::min(atoi(v), 2));
-    // (ppg_attn64.hip: built and parity-green, NOT the default -- at 32 x 1000 frames its long workgroups take 25 us
-    // against 21 and the 64 short ones a second round of 14 us on a quarter of the chip: DESIGN 4.2, profiles/r5_attn64_*)
-    e->attn64 = false;
-    if (const char* v = getenv("PPGS_AMD_ATTN64"))
-        e->attn64 = atoi(v) != 0 && e->head_dim == 128 && (cfg->precision == PPG_PRECISION_BF16 || cfg->precision == PPG_PRECISION_FP16);
-    if (const char* v = getenv("PPGS_AMD_HEAD32")) e->head32 = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_SUBTILE")) e->subtile = atoi(v) != 0;
+    e->op_fused = env_switch("PPGS_AMD_OP_FUSED", e->op_fused) != 0;
+    e->ffn_mixed = env_switch("PPGS_AMD_FFN_MIXED", e->ffn_mixed) != 0;
+    e->ffn_split_max = env_experiment("PPGS_AMD_FFN_SPLIT_MAX", e->ffn_split_max);
+    e->ffn_splits_forced = env_experiment("PPGS_AMD_FFN_SPLITS", e->ffn_splits_forced);
+    e->qkv_fused = env_switch("PPGS_AMD_QKV_FUSED", e->qkv_fused) != 0;
+    e->layer32 = env_switch("PPGS_AMD_LAYER32", e->layer32) != 0;
+    e->attn_xcd = env_experiment("PPGS_AMD_ATTN_XCD", e->attn_xcd) != 0;
+    e->attn_narrow = std::max(0, std::min(env_switch("PPGS_AMD_ATTN_NARROW", e->attn_narrow), 2));
+    e->head32 = env_switch("PPGS_AMD_HEAD32", e->head32) != 0;
+    e->subtile = env_switch("PPGS_AMD_SUBTILE", e->subtile) != 0;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_overflow), 256));
     HIP_OK(hipMemset(e->d_overflow, 0, 256));
-    e->x16 = cfg->precision == PPG_PRECISION_BF16;
-    if (const char* v = getenv("PPGS_AMD_X16")) e->x16 = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_OUTCONV")) e->outconv = atoi(v) != 0;
+    e->x16 = env_experiment("PPGS_AMD_X16", cfg->precision == PPG_PRECISION_BF16) != 0;
+    e->outconv = env_switch("PPGS_AMD_OUTCONV", e->outconv) != 0;
+    e->q_in_attn = env_switch("PPGS_AMD_Q_IN_ATTN", e->q_in_attn) != 0;
 #ifdef PPG_DEBUG_MODES
-    if (const char* v = getenv("PPGS_AMD_L32_DEBUG")) e->l32_debug = atoi(v);
-    if (const char* v = getenv("PPGS_AMD_H32_DEBUG")) e->h32_debug = atoi(v);
+    e->l32_debug = env_switch("PPGS_AMD_L32_DEBUG", 0);
+    e->h32_debug = env_switch("PPGS_AMD_H32_DEBUG", 0);
 #endif
     if (e->split) {
         // the unfused launch sequence: Q/K/V, attention, out-projection + LayerNorm, FFN as one launch each
@@ -984,23 +983,31 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     }
     if (!e->layer32 || H != 256 || e->Cp != 96 || !e->qkv_fused) e->head32 = false;
     if (e->sz != 2 || (H != 256 && H != 512) || F % 128 || F > 6656) e->layer32 = false;
+#ifdef PPG_LIN_TIMING
     if (const char* v = getenv("PPGS_AMD_LIN_TIMING")) {
         e->lin_dbg_class = atoi(v);
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->lin_dbg), 16 * 8192 * 8));
         HIP_OK(hipMemset(e->lin_dbg, 0, 16 * 8192 * 8));
     }
+#endif
+#ifdef PPG_ATTN_TIMING
     if (getenv("PPGS_AMD_ATTN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->attn_dbg), 512 + 4096 * 32));
         HIP_OK(hipMemset(e->attn_dbg, 0, 512 + 4096 * 32));
     }
+#endif
+#ifdef PPG_H32_TIMING
     if (getenv("PPGS_AMD_H32_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->head_dbg), 512));
         HIP_OK(hipMemset(e->head_dbg, 0, 512));
     }
+#endif
+#ifdef PPG_FFN_TIMING
     if (getenv("PPGS_AMD_FFN_TIMING")) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->ffn_dbg), 2048));
         HIP_OK(hipMemset(e->ffn_dbg, 0, 2048));
     }
+#endif
     if (e->ffn_nt < 0 || e->ffn_nt > 3) e->ffn_nt = 0;
     {
         hipDeviceProp_t prop;
@@ -1318,6 +1325,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     // sub-tile workgroups (two token blocks, three per tile) when whole tiles would leave two thirds of the CUs idle
     const bool sub32 = use32 && e->subtile && H == 256 && (F / 128) % 2 == 0 && 3 * tiles32 <= e->num_cus;
     const bool head = use32 && e->head32 && (2 * tiles32 >= e->num_cus || sub32);
+    const bool qx = use32 && head && !sub32 && e->q_in_attn && e->x16 && H == 256;     // Q rows made by the attention workgroups
     if (head) {
         Timed t(e, PPG_K_INCONV, s);
         Head32Args a{};
@@ -1331,6 +1339,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.debug_mode = e->h32_debug;
         a.x_half = e->x16;
         a.sub_tiles = sub32;
+        a.kv_only = qx;
         a.dbg = e->head_dbg;
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
@@ -1384,8 +1393,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.ao = ao; a.H = H; a.causal = c.is_causal;
             a.items = grp.d_items; a.win = grp.d_win; a.M = M; a.ao_tiled = use32; a.heads = c.heads;
             a.dbg = l == 0 ? e->attn_dbg : nullptr;
-            if (e->attn64) LAUNCH_OK(ppg::launch_attn64(prec, a, (int)grp.items.size(), c.heads, s), "attention");
-            else LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
+            LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
         if (use32) {
             Timed t(e, PPG_K_FFN, s);
@@ -1396,6 +1404,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.debug_mode = e->l32_debug;
             a.x_half = e->x16;
             a.sub_tiles = sub32;
+            a.kv_only = qx;
             qkv_done = e->qkv_fused && l + 1 < c.num_layers;
             a.write_x = l + 1 < c.num_layers;
             if (qkv_done) {
@@ -1594,8 +1603,8 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     HIP_OK(hipSetDevice(e->device));
     std::unique_ptr<PpgStream> st(new PpgStream);
     st->e = e; st->batch = batch; st->cap = max_frames; st->rows = round_up(max_frames, 32); st->dtype = feature_dtype;
-    if (const char* v = getenv("PPGS_AMD_STREAM_GRAPH")) st->graph_steps = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_STREAM_FUSED")) st->fused_layers = std::max(0, std::min(atoi(v), 2));
+    st->graph_steps = ppg::env_experiment("PPGS_AMD_STREAM_GRAPH", 0) != 0;
+    st->fused_layers = std::max(0, std::min(ppg::env_switch("PPGS_AMD_STREAM_FUSED", st->fused_layers), 2));
     st->received.assign(batch, 0); st->x_valid.assign(batch, 0); st->o_valid.assign(batch, 0); st->finished.assign(batch, 0);
     const PpgConfig& c = e->cfg;
     const int R = st->rows, MT = batch * R;
@@ -2038,7 +2047,7 @@ int ppg_w2v2_create(const PpgW2v2Weights* wts, int precision, int device, PpgW2v
                            &m->w[l]);
         if (rc) return rc;
     }
-    if (const char* v = getenv("PPGS_AMD_W2V2_CONV32")) m->conv32 = atoi(v) != 0;
+    m->conv32 = ppg::env_experiment("PPGS_AMD_W2V2_CONV32", m->conv32) != 0;
     if (E->sz != 2) m->conv32 = false;
     if (m->conv32) {
         // layers 1..6 as plain GEMMs on the feature-split kernel: output row m reads the k input rows 2 m .. as ONE
@@ -2211,8 +2220,8 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     E->num_cus = prop.multiProcessorCount;
     m->hidden = H; m->heads = w->heads; m->ffn = F; m->layers = L; m->taps = w->conv_kernel; m->groups = w->conv_groups;
     m->eps = w->layer_norm_eps;
-    if (const char* v = getenv("PPGS_AMD_W2V2_GEMM32")) m->gemm32 = atoi(v) != 0;
-    if (const char* v = getenv("PPGS_AMD_W2V2_QKV32")) m->qkv32 = atoi(v) != 0;
+    m->gemm32 = ppg::env_switch("PPGS_AMD_W2V2_GEMM32", m->gemm32) != 0;
+    m->qkv32 = ppg::env_experiment("PPGS_AMD_W2V2_QKV32", m->qkv32) != 0;
     if (E->sz != 2 || H % 256 || F % 256 || H % 128 || F % 128) m->gemm32 = false;
     const int CG = H / w->conv_groups;                       // 48 channels per group
     m->gpt = (CG * E->sz + 63) / 64;                         // K-groups of 64 bytes per tap: 2 (16-bit, padded) or 3 (fp32)
@@ -2252,7 +2261,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     }
     E->split = precision == PPG_PRECISION_FP16X2;
     if ((rc = upload_f32(E, w->pos_conv_bias, H, 0, &m->pos_b))) return rc;
-    if (const char* v = getenv("PPGS_AMD_W2V2_POSCONV")) m->posconv = atoi(v) != 0;
+    m->posconv = ppg::env_switch("PPGS_AMD_W2V2_POSCONV", m->posconv) != 0;
     if (E->sz != 2 || w->conv_groups != 16 || CG != 48 || m->taps != 128) m->posconv = false;
     if (m->posconv) {
         const float* pw = w->pos_conv_weight;
@@ -2325,7 +2334,7 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
     HIP_OK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-    if (const char* v = getenv("PPGS_AMD_W2V2_STREAMS")) m->pipelines = std::max(1, std::min(atoi(v), 2));
+    m->pipelines = std::max(1, std::min(ppg::env_switch("PPGS_AMD_W2V2_STREAMS", m->pipelines), 2));
     *out = m.release();
     return PPG_OK;
 }
@@ -2463,7 +2472,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
     } while (0)
     // tokens per wave (16 nt).  Measured at 16 x 499 frames, bf16: nt 1 4.41 ms, nt 2 4.82 ms, nt 3 6.35 ms
     int nt = std::min(choose_nt(E, M, 2), 2);
-    if (const char* v = getenv("PPGS_AMD_W2V2_NT")) nt = std::max(1, std::min(atoi(v), sz == 2 ? 3 : 2));
+    nt = std::max(1, std::min(ppg::env_experiment("PPGS_AMD_W2V2_NT", nt), sz == 2 ? 3 : 2));
     auto general = [&](const char* act, int k_elems, const char* W, const float* bias, int N) {
         LinearArgs a{};
         a.blk_win = d_blk; a.win = d_win; a.M = M; a.H = H; a.v_start = INT_MAX; a.taps = 1;
@@ -2504,7 +2513,7 @@ int body_forward_one(PpgW2v2Body* m, PpgW2v2Body::Slot& slot, const float* featu
         // (32 or 48 tokens per wave -- fewer re-reads of a group's 590 KB of weights -- measured: no faster, 3.20 / 3.24
         // against 3.23 ms per forward: the launch is bound by the re-reads of the ACTIVATION rows, one pass per tap)
         int pos_nt = 1;
-        if (const char* v = getenv("PPGS_AMD_W2V2_POS_NT")) pos_nt = std::max(1, std::min(atoi(v), sz == 2 ? 3 : 2));
+        pos_nt = std::max(1, std::min(ppg::env_experiment("PPGS_AMD_W2V2_POS_NT", pos_nt), sz == 2 ? 3 : 2));
         LAUNCH_OK(ppg::launch_linear(E->split ? PPG_PRECISION_FP32 : prec, EPI_GENERAL, 3, pos_nt, a, m->groups, s), "w2v2 positional convolution");
         LAUNCH_OK(layer_norm(m->en_g, m->en_b), "w2v2 encoder LayerNorm");
         }
@@ -2596,20 +2605,7 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
         return fail(PPG_EINVAL, "frontend: batch %d x 513 bins x %d frames does not fit the kernel's 32-bit output index", batch, samples / 160);
     hipError_t he = ppg::launch_frontend(f->tb, audio, batch, samples, spec, mel, s);
     if (on) (void)hipEventRecord(ev.b, s);
-    if (f->tb.dbg && getenv("PPGS_AMD_FE_CHECK")) {
-        unsigned long long h[64];
-        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, f->tb.dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && (h[0] || h[1] || h[2] || h[4] || h[5] || h[6] || h[7] || getenv("PPGS_AMD_FE_CHECK_VERBOSE"))) {
-            fprintf(stderr, "frontend check: %llu transforms checked, %llu dwords of a repeated transform differ from the first; split stage: %llu / %llu re-reads of Z[k] / Z[N-k] differ, %llu recomputed magnitudes differ\n", h[3], h[4], h[5], h[6], h[7]);
-            fprintf(stderr, "frontend check: %llu twiddle reads and %llu sample reads from LDS differ from memory, %llu pass-3 inputs differ from the writers' registers\n", h[0], h[1], h[2]);
-            for (int n = 0; n < 6 && n < (int)h[2]; ++n)
-                fprintf(stderr, "   pass-3 input (m, jj, lane, pair) %llu: got %08llx %08llx want %08llx %08llx (workgroup*1000+round %llu)\n", h[32 + 4 * n], h[33 + 4 * n] >> 32, h[33 + 4 * n] & 0xffffffffull,
-                        h[34 + 4 * n] >> 32, h[34 + 4 * n] & 0xffffffffull, h[35 + 4 * n]);
-            for (int n = 0; n < 6 && n < (int)h[0]; ++n)
-                fprintf(stderr, "   twiddle %llu: got %08llx %08llx want %08llx %08llx (workgroup*1000+round %llu)\n", h[8 + 4 * n], h[9 + 4 * n] >> 32, h[9 + 4 * n] & 0xffffffffull,
-                        h[10 + 4 * n] >> 32, h[10 + 4 * n] & 0xffffffffull, h[11 + 4 * n]);
-            (void)hipMemset(f->tb.dbg, 0, 512);
-        }
-    } else if (f->tb.dbg) {
+    if (f->tb.dbg) {
         static int dumps = 0;
         unsigned long long h[64];
         if (dumps++ < 2 && hipStreamSynchronize(s) == hipSuccess &&

@@ -60,17 +60,9 @@ constexpr int OFF_FFT = OFF_SEG + 2 * SEGP * 4;             // float2[4][BUF]
 constexpr int OFF_MAG = OFF_FFT + 4 * BUF * 8;              // fp16 rows [16][MROW / 2]
 constexpr int LDS_BYTES = OFF_MAG + FPB * MROW;
 // Four-wave teams per workgroup.  The product is 2: a 512-thread workgroup that requests the CU's whole LDS, so no other
-// kernel's workgroup can sit beside it.  -DPPG_FE_R2 rebuilds round 2's launch -- one team, 256 threads,
-// 79.5 KiB, two workgroups per CU or one beside another kernel's -- as the REPRODUCER of the co-residency failure for
-// tools/frontend_race_probe.py / tools/coresidency_matrix.py; it is never the product.
-#ifdef PPG_FE_R2
-constexpr int TEAMS = 1;
-#else
+// kernel's workgroup can sit beside it (round 2's launch -- one team of 256 threads and 79.5 KiB per
+// workgroup -- was where the gfx950 hazard of DESIGN 4.4 was found: tools/probes/pk_mfma_probe.hip reproduces it alone).
 constexpr int TEAMS = 2;
-#endif
-#ifndef PPG_FE_MIN_BLOCKS
-#define PPG_FE_MIN_BLOCKS (2 / TEAMS)
-#endif
 constexpr int CU_LDS_BYTES = 163840;
 static_assert(2 * LDS_BYTES <= CU_LDS_BYTES && LDS_BYTES % 16 == 0, "two teams per CU; a two-team workgroup = the CU's LDS");
 static_assert(OFF_MAG % 16 == 0 && MROW % 16 == 0, "fragment reads are 16-byte aligned");
@@ -91,29 +83,6 @@ static_assert(OFF_MAG % 16 == 0 && MROW % 16 == 0, "fragment reads are 16-byte a
 typedef float cplx __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return a + b; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return a - b; }
-#ifdef PPG_FE_PLAIN_COMPLEX
-__device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) { return cplx{a.x + b.y, a.y - b.x}; }
-__device__ __forceinline__ cplx csub_mi(cplx a, cplx b) { return cplx{a.x - b.y, a.y + b.x}; }
-__device__ __forceinline__ cplx cmul(cplx a, cplx w) { return cplx{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-#elif defined(PPG_FE_R2_ARITH)
-// round 2's forms (source 1 swapped): the reproducer's arithmetic, with -DPPG_FE_R2
-__device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) {
-    cplx r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ cplx csub_mi(cplx a, cplx b) {
-    cplx r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ cplx cmul(cplx a, cplx w) {
-    cplx t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;
-}
-#else
 // a + (-i) b = (b.y + a.x, -b.x + a.y): b, swapped, is source 0
 __device__ __forceinline__ cplx cadd_mi(cplx a, cplx b) {
     cplx r;
@@ -134,7 +103,6 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx w) {
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "v"(a.y), "v"(w.x), "v"(t.y));
     return r;
 }
-#endif
 
 // forward 4-point DFT, in place: (A, B, C, D) -> (X0, X1, X2, X3); CMI: the input C is (-i) C
 template <bool CMI = false>
@@ -182,11 +150,9 @@ __device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
 // LDS exchanges between the lanes of one wave.  The writes must have COMPLETED before another lane's read of them
 // is issued: lgkmcnt(0).  (Round 2 relied on "a wave's LDS operations execute in order" and only stopped the
 // compiler from moving them; that holds on a quiet CU and fails beside another kernel's LDS traffic -- a frame
-// pair whose conjugate-symmetry split read the partner bins of the previous pass, tools/frontend_race_probe.py.)
+// pair whose conjugate-symmetry split read the partner bins of the previous pass, HISTORY.md, round 2.)
 __device__ __forceinline__ void wave_sync() {
-#ifndef PPG_FE_NO_LGKM_WAIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -198,21 +164,18 @@ __device__ __forceinline__ void wave_sync() {
 // 256-thread workgroups per CU, and no other kernel's workgroup can share the CU.  That is a correctness matter:
 // beside the encoder's kernels on another stream (attention's 64 KiB workgroups fit next to one 80 KiB workgroup) a
 // frame pair's transform came out wrong about once per 300 pairs -- one VALU result of 16 or 64 lanes, different on
-// a repeat of the same transform from the same LDS inputs (tools/frontend_race_probe*.py, -DPPG_FE_CHECK: samples,
+// a repeat of the same transform from the same LDS inputs (-DPPG_FE_CHECK: samples,
 // twiddles and the pass-2 -> pass-3 exchange verified intact, workgroup barriers between the passes and plain C++
 // complex arithmetic change nothing, a CU of its own gives 0 of 240 launches wrong against 160).  The two teams
 // share nothing but the barriers.
 template <bool SPEC>
-__global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kernel(
+__global__ __launch_bounds__(256 * TEAMS, 2 / TEAMS) void frontend_kernel(
     ppg::FrontendTables tb, const float* __restrict__ audio, int samples, int frames,
     int groups_per_row, int total_groups, int wide_ok, __half* __restrict__ spec, __half* __restrict__ mel)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int team = TEAMS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     char* smem = smem_all + team * LDS_BYTES;
-#ifdef PPG_FE_SETPRIO
-    __builtin_amdgcn_s_setprio(PPG_FE_SETPRIO);
-#endif
     cplx* tw = reinterpret_cast<cplx*>(smem + OFF_TW);
     float* seg0 = reinterpret_cast<float*>(smem + OFF_SEG);
 
@@ -325,17 +288,6 @@ __global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kerne
                 for (int i = 0; i < 16; ++i) {
                     x[i] = cplx{sa[64 * i], sa[64 * i + HOP]} * hreg[i];
                 }
-#ifdef PPG_FE_CHECK
-                {
-                    const int first = f0 * HOP - PADR;
-                    if (tb.dbg && first >= 0 && first + SEGP <= samples) {
-                        const float* src = audio + (size_t)b * samples + first + (2 * j) * HOP + lane;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (sa[64 * i] != src[64 * i] || sa[64 * i + HOP] != src[64 * i + HOP]) atomicAdd(tb.dbg + 1, 1ull);
-                    }
-                }
-#endif
                 dft16(x);
 #pragma unroll
                 for (int k = 1; k < 16; ++k) x[k] = cmul(x[k], t1[k]);
@@ -353,18 +305,6 @@ __global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kerne
                 for (int i = 0; i < 16; ++i) x[i] = buf[p0 + 68 * i];           // pad(l + 64 i)
                 dft16(x);
                 const int p = lane >> 4, q = lane & 15;
-#ifdef PPG_FE_CHECK
-#pragma unroll
-                for (int k = 1; k < 16; ++k) {
-                    const cplx w = tw[p * k];
-                    const float2 ref = tb.twiddle[16 * p * k];
-                    if (tb.dbg && (w.x != ref.x || w.y != ref.y)) {
-                        const unsigned long long n = atomicAdd(tb.dbg, 1ull);
-                        if (n < 6) { tb.dbg[8 + 4 * n] = (unsigned long long)(p * k); tb.dbg[9 + 4 * n] = ((unsigned long long)__float_as_uint(w.x) << 32) | __float_as_uint(w.y);
-                                     tb.dbg[10 + 4 * n] = ((unsigned long long)__float_as_uint(ref.x) << 32) | __float_as_uint(ref.y); tb.dbg[11 + 4 * n] = (unsigned long long)blockIdx.x * 1000 + grp / stride; }
-                    }
-                }
-#endif
 #pragma unroll
                 for (int k = 1; k < 16; ++k) x[k] = cmul(x[k], tw[p * k]);       // W1024^(16 p k)
                 cplx* dst = buf + q + 272 * p;                                  // pad(q + 256 p + 16 k) = q + 272 p + 17 k
@@ -372,30 +312,6 @@ __global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kerne
                 for (int k = 0; k < 16; ++k) dst[17 * k] = x[k];
             }
             wave_sync();
-#ifdef PPG_FE_CHECK
-            // what pass 3 is about to read against what the writer lanes hold in registers (shuffles: not LDS memory)
-            if (tb.dbg) {
-                if (lane == 0) atomicAdd(tb.dbg + 3, 1ull);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const cplx got = buf[p0 + 68 * m + 272 * jj];
-                        cplx want = cplx{0.f, 0.f};
-#pragma unroll
-                        for (int gsel = 0; gsel < 4; ++gsel) {
-                            const float tx = __shfl(x[gsel + 4 * m].x, 16 * jj + (lane & 15));
-                            const float ty = __shfl(x[gsel + 4 * m].y, 16 * jj + (lane & 15));
-                            if ((lane >> 4) == gsel) want = cplx{tx, ty};
-                        }
-                        if (__float_as_uint(got.x) != __float_as_uint(want.x) || __float_as_uint(got.y) != __float_as_uint(want.y)) {
-                            const unsigned long long n = atomicAdd(tb.dbg + 2, 1ull);
-                            if (n < 6) { tb.dbg[32 + 4 * n] = (unsigned long long)(m * 1000000 + jj * 10000 + lane * 100 + j); tb.dbg[33 + 4 * n] = ((unsigned long long)__float_as_uint(got.x) << 32) | __float_as_uint(got.y);
-                                         tb.dbg[34 + 4 * n] = ((unsigned long long)__float_as_uint(want.x) << 32) | __float_as_uint(want.y); tb.dbg[35 + 4 * n] = (unsigned long long)blockIdx.x * 1000 + grp / stride; }
-                        }
-                    }
-            }
-#endif
             // pass 3: radix 4, stride 256, no twiddles; lane l owns q = l + 64 m
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -437,12 +353,6 @@ __global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kerne
                 const uint32_t pk = (uint32_t)__half_as_ushort(ha) | ((uint32_t)__half_as_ushort(hb) << 16);
                 const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xB1, 0xf, 0xf, true);   // lane ^ 1
                 const uint32_t val = __builtin_amdgcn_perm(pk, other, sel);
-#ifdef PPG_FE_CHECK
-                if (verify) {          // second computation of the same pair: must reproduce what the first one stored
-                    if (tb.dbg && *reinterpret_cast<uint32_t*>(wdst + 128 * r) != val) atomicAdd(tb.dbg + 4, 1ull);
-                    continue;
-                }
-#endif
                 *reinterpret_cast<uint32_t*>(wdst + 128 * r) = val;
             }
             if (verify) return;
@@ -455,16 +365,10 @@ __global__ __launch_bounds__(256 * TEAMS, PPG_FE_MIN_BLOCKS) void frontend_kerne
         };
 
         transform(wave);
-#ifdef PPG_FE_CHECK
-        transform(wave, true);
-#endif
         stamp(2);
         if (!(wide_ok & 4) && grp + stride < total_groups) stage(grp + stride, half ^ 1);    // free since the barrier above: it held the previous group
         stamp(3);
         transform(wave + 4);
-#ifdef PPG_FE_CHECK
-        transform(wave + 4, true);
-#endif
         stamp(4);
         // the wave's weight fragments (40 KB for all four waves, L2 / L1 resident): requested here, they
         // arrive while the workgroup gathers at the barrier -- held across the transforms they would
@@ -549,11 +453,10 @@ hipError_t launch_frontend(const FrontendTables& tb, const float* audio, int bat
     // the product workgroup asks for ALL of the CU's LDS (not just its two teams' 2 x 79.5 KiB): a kernel that needs
     // <= 1 KiB of LDS would otherwise still fit beside it
     size_t lds_bytes = TEAMS == 2 ? CU_LDS_BYTES : LDS_BYTES;
-    static const int fe_debug = getenv("PPGS_AMD_FE_DEBUG") ? atoi(getenv("PPGS_AMD_FE_DEBUG")) : 0;   // 1: narrow DMA only, 4: serial staging
+    static const int fe_debug = env_experiment("PPGS_AMD_FE_DEBUG", 0);   // 1: narrow DMA only, 4: serial staging, 16: the exact LDS request
     if (fe_debug & 1) wide_ok = 0;
     if (fe_debug & 4) wide_ok |= 4;
-    if (fe_debug & 8) lds_bytes = CU_LDS_BYTES;    // (repro variant: the one-team workgroup alone on its CU)
-    if (fe_debug & 16) lds_bytes = TEAMS * LDS_BYTES;   // (product variant with the exact request: small-LDS kernels may co-reside)
+    if (fe_debug & 16) lds_bytes = TEAMS * LDS_BYTES;   // (small-LDS kernels may then co-reside)
     if (spec)
         hipLaunchKernelGGL(frontend_kernel<true>, dim3(grid), dim3(256 * TEAMS), lds_bytes, s, tb, audio, samples, frames,
                            groups_per_row, total, wide_ok, reinterpret_cast<__half*>(spec), reinterpret_cast<__half*>(mel));

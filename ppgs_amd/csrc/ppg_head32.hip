@@ -33,7 +33,7 @@ struct OffIn {
     }
 };
 
-template <class P, int TBS>
+template <class P, int TBS, bool KVONLY = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void head32_kernel(Head32Args a) {
     using G = Geo<HID, TBS>;
     constexpr int RB = G::RB, KS = G::KS, TB = G::TBN, TOKS = G::TOKS;
@@ -88,22 +88,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert((TOKS + 2 * HALO) * ROWB <= TB * 8 * 1024, "the gathered tile fits the h region");
     float* bq_lds = reinterpret_cast<float*>(smem + G::L_BQ);
 
+#ifdef PPG_H32_TIMING
     auto pstamp = [&](int k) {
         if (!SUB && a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[wave * 16 + k] = __builtin_amdgcn_s_memtime();
     };
+#else
+    auto pstamp = [&](int) {};
+#endif
     pstamp(0);
     u32x4 w1f[16], w2f[16];
     auto load16 = [&](u32x4 (&wf)[16], const char* base) {
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
     };
     const char* wimg = a.win_img + ((size_t)wave * RB * KSI) * 1024;
-    const char* wq0 = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
-#ifndef PPG_HEAD_W_OLD
+    const char* wq0 = a.wq_img + ((size_t)wave * 3 * RB * KS + 16 * qkv_first_half_step<HID, KVONLY ? 1 : 0>()) * 1024;
     // the convolution's first-round weight fragments travel under the gather (nothing below touches the two register
     // sets before the round's wait: tools/asm_load_scan.py checks the built code)
     load16(w1f, wimg);
     load16(w2f, wimg + (size_t)KSI * 1024);
-#endif
 
     // ---- 1. gather: thread r < TOKS + 2 HALO takes row r = token m0 - HALO + r, all channels (for one channel,
     // neighbouring threads read neighbouring frames)
@@ -181,10 +183,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto round = [&](auto r_tag, auto after_wait) {
         constexpr int R = decltype(r_tag)::value;
         // (16 fragments are fetched where KSH = 15 are used: the image carries one pad fragment at its end)
-#ifdef PPG_HEAD_W_OLD
-        load16(w1f, wimg + (size_t)(KSH * R) * 1024);
-        load16(w2f, wimg + (size_t)(KSI + KSH * R) * 1024);
-#endif
         vm_wait_all(w1f);
         vm_wait_all(w2f);
         after_wait();
@@ -206,13 +204,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 yacc[0][tb] = P::mma32(w1f[ksl], b, yacc[0][tb]);
                 yacc[1][tb] = P::mma32(w2f[ksl], b, yacc[1][tb]);
             }
-#ifndef PPG_HEAD_W_OLD
             // the second round's fragment ksl is requested behind the first round's last use of its registers
             if constexpr (R == 0 && tb == TB - 1) {
                 gload_frag<ksl>(w1f[ksl], voff, wimg + (size_t)KSH * 1024);
                 gload_frag<ksl>(w2f[ksl], voff, wimg + (size_t)(KSI + KSH) * 1024);
             }
-#endif
         });
     };
     if (!(PPG_DBG(a) & 1)) round(std::integral_constant<int, 0>{}, [] {});
@@ -272,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Layer32Args la{};
     la.wq_img = a.wq_img; la.qk_out = a.qk_out; la.vt_out = a.vt_out; la.vt_ld = a.vt_ld;
     la.blk_win = a.blk_win; la.win = a.win; la.M = a.M; la.H = HID;
-    if (!(PPG_DBG(a) & 2)) qkv_tail<P, HID, TBS>(la, smem, m0, w1f, w2f, nblk);
+    if (!(PPG_DBG(a) & 2)) qkv_tail<P, HID, TBS, KVONLY ? 1 : 0>(la, smem, m0, w1f, w2f, nblk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pstamp(7);
 }
@@ -294,6 +290,12 @@ hipError_t launch_head32(int precision, const Head32Args& a, hipStream_t s) {
         return hipGetLastError();
     };
     constexpr int T5 = tile_blocks(HID);
+    if (a.kv_only) {       // (whole tiles only)
+        if (a.sub_tiles) return hipErrorInvalidValue;
+        if (precision == PPG_PRECISION_BF16) return launch(head32_kernel<PrecBF16, T5, true>, Geo<HID>{}, 1);
+        if (precision == PPG_PRECISION_FP16) return launch(head32_kernel<PrecF16, T5, true>, Geo<HID>{}, 1);
+        return hipErrorInvalidValue;
+    }
     if (precision == PPG_PRECISION_BF16) return a.sub_tiles ? launch(head32_kernel<PrecBF16, 2>, Geo<HID, 2>{}, 3) : launch(head32_kernel<PrecBF16, T5>, Geo<HID>{}, 1);
     if (precision == PPG_PRECISION_FP16) return a.sub_tiles ? launch(head32_kernel<PrecF16, 2>, Geo<HID, 2>{}, 3) : launch(head32_kernel<PrecF16, T5>, Geo<HID>{}, 1);
     return hipErrorInvalidValue;

@@ -1364,23 +1364,14 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
     // (wave-uniform by construction; said so, the row-map entry is a scalar load -- it does not queue behind the
     // vector loads of the partial sums, which return in issue order)
     const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 4
-    const int m = slot;
-#else
     const int m = a.rowmap ? a.rowmap[slot >> 4] + (slot & 15) : slot;          // (row map: only the rows of the step)
-#endif
-#if !defined(PPG_REDUCE_ABL)
     if (a.H == 256 && splits <= 8) {
         // (the row-map entry and the partial rows travel together; a row past M is computed and not stored)
         reduce_ln_rows<P, 1>(a, splits, a.rowmap ? slot : min(slot, a.M - 1), m, lane,
                              (size_t)(a.rowmap ? (a.map_blocks + 3) / 4 * 64 : a.M) * 256);
         return;
     }
-#endif
     if (m >= a.M) return;
-#if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 3
-    if (m >= 0) return;
-#endif
     const int H = a.H;
     float4 v[2];
     float sum = 0.f;
@@ -1404,11 +1395,9 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
                 for (int j = 0; j < N; ++j) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
             }
         };
-#if !defined(PPG_REDUCE_ABL) || PPG_REDUCE_ABL != 1
         batch(std::integral_constant<int, 8>{});
         batch(std::integral_constant<int, 4>{});
         batch(std::integral_constant<int, 1>{});
-#endif
         v[h] = acc;
         sum += (acc.x + acc.y) + (acc.z + acc.w);
     }
@@ -1431,9 +1420,6 @@ __global__ __launch_bounds__(256) void ffn_reduce_ln_kernel(FfnArgs a, int split
         const float y1 = (v[h].y - mean) * rstd * gv.y + ev.y;
         const float y2 = (v[h].z - mean) * rstd * gv.z + ev.z;
         const float y3 = (v[h].w - mean) * rstd * gv.w + ev.w;
-#if defined(PPG_REDUCE_ABL) && PPG_REDUCE_ABL == 2
-        if (y0 != 12345.678f) continue;
-#endif
         *reinterpret_cast<float4*>(a.X + (size_t)m * H + n) = make_float4(y0, y1, y2, y3);
         if constexpr (P::kIsBF16 || P::kSplit) store4<P>(a.Xb + (size_t)m * H * P::kBytes + P::row_byte(n), y0, y1, y2, y3);
     }
@@ -1478,20 +1464,6 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 
     // Q fragments
     u32x4 qf[DG][NTQ];
-#ifdef PPG_ATTN_WAIT_ALL
-#pragma unroll
-    for (int t = 0; t < NTQ; ++t) {
-        const int tq = qw0 + 16 * t + idx;
-        const int m = w.tok_off + tq;
-        const bool ok = (qw0 + 16 * t) < ((w.frames + 15) & ~15);   // inside the window's padded rows
-#pragma unroll
-        for (int kg = 0; kg < DG; ++kg) {
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(a.qk + (size_t)m * a.qk_ld_bytes + (size_t)head * ROWK + kg * 64 + g * 16);
-            qf[kg][t] = v;
-        }
-    }
-#else
     // requested by hand (the compiler, blind to the tile DMAs issued behind them, would wait for its own loads with
     // vmcnt(0) -- for every tile of the prologue -- at the first score MFMA): unconditional, a block past the window's
     // padded rows reads the window's first row and is zeroed behind the wait
@@ -1505,7 +1477,6 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
         for (int kg = 0; kg < DG; ++kg)
             asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[kg][t]) : "v"(src), "n"(kg * 64) : "memory");
     }
-#endif
 
     int kend = w.valid;                              // keys >= valid are masked
     if (a.causal) kend = min(kend, item.q0 + NW * 16 * NTQ);
@@ -1654,11 +1625,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
     // kt + 1 and accumulates tile kt -- the exponentials of a tile no longer have to fit between the MFMAs of ONE
     // phase (they rode on the score MFMAs only, clumped ~14 instructions to a step, while the P V MFMAs ran bare), they
     // are spread as micro-operations (two exponentials, their sum, one pack) over BOTH phases, one to every other step.
-#ifdef PPG_ATTN_2STAGE
-    constexpr bool STAGE3 = false;
-#else
     constexpr bool STAGE3 = P::kIsBF16 && !P::kSplit && NTQ == 1;      // (32 queries per wave: 256 registers do not hold a third tile's state)
-#endif
     // micro-operation u = (t, kb, h): p of the scores 2 h, 2 h + 1 of key block kb for query block t
     constexpr int NUOP = NTQ * KB * 2;
     auto exp_half = [&](auto u_tag, f32x4 (&s)[KB][NTQ], u32x4 (&pf)[PG][NTQ]) {
@@ -1681,9 +1648,6 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
 
     if (ntiles > 0) { stage_k(0); stage_v(0); }
     if (ntiles > 1) stage_k(1);
-#ifdef PPG_ATTN_WAIT_ALL
-    dma_wait_barrier();
-#else
     // the first scores need the Q rows and K tile 0 only: V^T tile 0 and K tile 1 (the younger requests: vector-memory
     // operations complete in issue order) travel on under them
     {
@@ -1701,7 +1665,6 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             }
         __syncthreads();
     }
-#endif
 
     f32x4 scur[KB][NTQ], snext[KB][NTQ];
     if (ntiles > 0) {
@@ -1721,9 +1684,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const AttnItem& ite
             }
         }
     }
-#ifndef PPG_ATTN_WAIT_ALL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // V^T tile 0, K tile 1
-#endif
     __syncthreads();                       // K buffer 0 is re-filled by iteration 0's DMA
 
 #ifdef PPG_ATTN_TIMING

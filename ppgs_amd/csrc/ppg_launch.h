@@ -2,11 +2,28 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "ppg_device.h"
 
 namespace ppg {
+
+// Kernel-selection switches of the environment.  The product library reads only the ones the parity tests drive
+// (env_switch: each A/Bs a kernel against the path it replaced, tests/test_gpu_parity.py names them); tile-shape
+// overrides, schedule experiments and the stamps of the timing builds exist in -DPPG_EXPERIMENT_SWITCHES builds only
+// (make VARIANT=exp EXTRA=-DPPG_EXPERIMENT_SWITCHES).  INTEGRATION.md lists both sets.
+inline int env_switch(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+#ifdef PPG_EXPERIMENT_SWITCHES
+inline int env_experiment(const char* name, int dflt) { return env_switch(name, dflt); }
+inline bool env_experiment_set(const char* name) { return getenv(name) != nullptr; }
+#else
+inline int env_experiment(const char*, int dflt) { return dflt; }
+inline bool env_experiment_set(const char*) { return false; }
+#endif
 
 int attn_query_tile(int head_dim);   // queries per attention workgroup
 
@@ -19,10 +36,6 @@ hipError_t launch_linear(int precision, int epi, int nb, int nt, const LinearArg
 constexpr int kFfnMixedTiling = 5;
 hipError_t launch_ffn(int precision, const FfnArgs& a, int nt, hipStream_t s);
 hipError_t launch_attn(int precision, const AttnArgs& a, int nitems, int heads, int head_dim, hipStream_t s);
-// attention at head dimension 128, 16-bit precisions, as 256-query workgroups of one wave per SIMD (ppg_attn64.hip);
-// items are (window, q0) with q0 a multiple of attn64_query_tile()
-int attn64_query_tile();
-hipError_t launch_attn64(int precision, const AttnArgs& a, int nitems, int heads, hipStream_t s);
 // feature-split layer kernel (ppg_layer32.hip): 16-bit precisions, hidden 256, F a multiple of 128
 hipError_t launch_layer32(int precision, const Layer32Args& a, hipStream_t s);
 // gather + input convolution + layer 0's Q/K/V of a 160-token tile (ppg_head32.hip): 16-bit precisions, hidden 256, <= 96 input channels

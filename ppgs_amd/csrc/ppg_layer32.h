@@ -193,12 +193,20 @@ __device__ __forceinline__ void panel_store(uint32_t pb0, int wave, int t, int r
 // step, on top of 1.4 - 3.2 k cycles of epilogue with the matrix pipe idle).  The count is exact only in a tile
 // whose rows all exist and whose token blocks are whole 32-token groups of V^T (`regular`: every tile of a
 // batch of 32-aligned windows); any other tile waits with vmcnt(0).
-template <class P, int HIDT, int TBS = tile_blocks(HIDT)>
+//
+// KIND0 = 1: K and V only -- the attention workgroups compute their Q rows themselves from the fp16 residual rows
+// (X16 order: they ARE 32x32x16 B operands) and W_q (ppg_kernels.hip, attn_body's QX prologue): a third of the tail's
+// stores and MFMAs gone.  The caller then hands over the fragments of half-step qkv_first_half_step<..>() in w1f.
+template <int HIDT, int KIND0>
+constexpr int qkv_first_half_step() { return KIND0 * (HIDT / 128) * (HIDT / 256); }
+template <class P, int HIDT, int TBS = tile_blocks(HIDT), int KIND0 = 0>
 __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const int m0, u32x4 (&w1f)[16], u32x4 (&w2f)[16],
                                          const int nblk = TBS) {
     using G = Geo<HIDT, TBS>;
     constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
     constexpr int NSTEP = 3 * RB, NHS = NSTEP * KH;
+    constexpr int STEP0 = KIND0 * RB, HS0 = STEP0 * KH;        // (both even: the register and accumulator sets alternate as from 0)
+    static_assert(HS0 == qkv_first_half_step<HIDT, KIND0>() && HS0 % 2 == 0 && STEP0 % 2 == 0, "tail entry");
     constexpr int NMMA = 16 * TB;                           // MFMAs (= stream steps) of a half-step
     constexpr int NU = 2 * TB;                              // epilogue units (one 16-byte store each in a regular tile)
     constexpr int USTRIDE = (NMMA - 16) / NU;
@@ -246,17 +254,11 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             b4[0] = make_float4(bv, bv, bv, bv);
         }
     };
-    // The bias is the C operand of a step's first MFMAs (-DPPG_TAIL_BIAS_IN_UNIT: added in the epilogue units, the form
-    // until round 5 -- 16 v_add_f32 per unit pair in slots that hide ~8 instructions each)
-#ifdef PPG_TAIL_BIAS_IN_UNIT
-    auto bias_in_unit = [](float b) { return b; };
-#else
-    auto bias_in_unit = [](float) { return -0.0f; };            // (x + -0.0f folds away; x + 0.0f does not: -0 + 0 = +0)
-#endif
+    // The bias is the C operand of a step's first MFMAs (added in the epilogue units it was 16 v_add_f32 per unit pair
+    // in slots that hide ~8 instructions each)
     auto bias_c = [&](auto step_tag) {
         constexpr int STEP = decltype(step_tag)::value;
         f32x16 cinit = zero;
-#ifndef PPG_TAIL_BIAS_IN_UNIT
         float4 bb[4];
         bias_of(step_tag, bb);
         if constexpr (STEP / RB < 2) {
@@ -266,16 +268,14 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
 #pragma unroll
             for (int k = 0; k < 16; ++k) cinit[k] = bb[0].x;
         }
-#endif
         return cinit;
     };
     u32x4 held = u32x4{0u, 0u, 0u, 0u};
     // epilogue unit U (token block U / 2, half U % 2) of step STEP from its accumulator set
-    auto unit = [&](auto step_tag, auto u_tag, const float4 (&b4)[4]) {
+    auto unit = [&](auto step_tag, auto u_tag) {
         constexpr int STEP = decltype(step_tag)::value, U = decltype(u_tag)::value;
         constexpr int KIND = STEP / RB, RBI = STEP % RB, t = U / 2, s2 = U % 2;
         const f32x16& c = acc[STEP & 1][t];
-#ifndef PPG_TAIL_NO_SWAP
         // A regular tile stores a block's two halves together, after ONE v_permlane16_swap per dword: the accumulator
         // layout hands a lane 32 bytes of one row (two 16-byte stores whose instruction covers 32 rows x 2 pieces 32
         // bytes apart); swapping the 16-lane rows of the two packed registers gives one register the four 16-byte
@@ -286,14 +286,13 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         if (regular) {
             u32x4 r;
             if constexpr (KIND < 2) {
-                r = u32x4{P::pack2(c[8 * s2 + 0] + bias_in_unit(b4[2 * s2].x), c[8 * s2 + 1] + bias_in_unit(b4[2 * s2].y)),
-                          P::pack2(c[8 * s2 + 2] + bias_in_unit(b4[2 * s2].z), c[8 * s2 + 3] + bias_in_unit(b4[2 * s2].w)),
-                          P::pack2(c[8 * s2 + 4] + bias_in_unit(b4[2 * s2 + 1].x), c[8 * s2 + 5] + bias_in_unit(b4[2 * s2 + 1].y)),
-                          P::pack2(c[8 * s2 + 6] + bias_in_unit(b4[2 * s2 + 1].z), c[8 * s2 + 7] + bias_in_unit(b4[2 * s2 + 1].w))};
+                r = u32x4{P::pack2(c[8 * s2 + 0], c[8 * s2 + 1]),
+                          P::pack2(c[8 * s2 + 2], c[8 * s2 + 3]),
+                          P::pack2(c[8 * s2 + 4], c[8 * s2 + 5]),
+                          P::pack2(c[8 * s2 + 6], c[8 * s2 + 7])};
             } else {
-                const float bv = bias_in_unit(b4[0].x);
-                r = u32x4{P::pack2(c[4 * s2 + 0] + bv, c[4 * s2 + 1] + bv), P::pack2(c[4 * s2 + 2] + bv, c[4 * s2 + 3] + bv),
-                          P::pack2(c[4 * (s2 + 2) + 0] + bv, c[4 * (s2 + 2) + 1] + bv), P::pack2(c[4 * (s2 + 2) + 2] + bv, c[4 * (s2 + 2) + 3] + bv)};
+                r = u32x4{P::pack2(c[4 * s2 + 0], c[4 * s2 + 1]), P::pack2(c[4 * s2 + 2], c[4 * s2 + 3]),
+                          P::pack2(c[4 * (s2 + 2) + 0], c[4 * (s2 + 2) + 1]), P::pack2(c[4 * (s2 + 2) + 2], c[4 * (s2 + 2) + 3])};
             }
             if constexpr (s2 == 0) {
                 held = r;
@@ -319,54 +318,41 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             }
             return;
         }
-#endif
         if constexpr (KIND < 2) {
             // Q / K: row m, features HIDT * KIND + fbase + 32 RBI + 16 hh + 8 s2 .. + 7
             const int m = m0 + 32 * t + tok;
             if (m < a.M && t < nblk) {
                 char* dst = a.qk_out + ((size_t)m * 2 * HIDT + HIDT * KIND + 32 * RBI + fbase + 16 * hh) * 2;
-                const float4 ba = b4[2 * s2], bb = b4[2 * s2 + 1];
                 *reinterpret_cast<u32x4*>(dst + 16 * s2) = u32x4{
-                    P::pack2(c[8 * s2 + 0] + bias_in_unit(ba.x), c[8 * s2 + 1] + bias_in_unit(ba.y)), P::pack2(c[8 * s2 + 2] + bias_in_unit(ba.z), c[8 * s2 + 3] + bias_in_unit(ba.w)),
-                    P::pack2(c[8 * s2 + 4] + bias_in_unit(bb.x), c[8 * s2 + 5] + bias_in_unit(bb.y)), P::pack2(c[8 * s2 + 6] + bias_in_unit(bb.z), c[8 * s2 + 7] + bias_in_unit(bb.w))};
+                    P::pack2(c[8 * s2 + 0], c[8 * s2 + 1]), P::pack2(c[8 * s2 + 2], c[8 * s2 + 3]),
+                    P::pack2(c[8 * s2 + 4], c[8 * s2 + 5]), P::pack2(c[8 * s2 + 6], c[8 * s2 + 7])};
             }
         } else {
             // V: lane = V^T row fbase + 32 RBI + (l & 31) (natural feature pair_row(row): attn_kernel's tile order),
             // registers = tokens 8 q + 4 hh + r of the block.  attn_kernel wants the columns of every 32-token group
             // of a window at position 8 g + 4 e + r for token 16 e + 4 g + r.
-            const float bv = bias_in_unit(b4[0].x);
             char* rowp = a.vt_out + (size_t)(fbase + 32 * RBI + tok) * a.vt_ld * 2;
             if (valigned[t]) {            // the block is one 32-token group: (q, q + 2) are 8 consecutive columns
                 *reinterpret_cast<u32x4*>(rowp + (size_t)(vcol[t][0] + 16 * s2 + 8 * hh) * 2) = u32x4{
-                    P::pack2(c[4 * s2 + 0] + bv, c[4 * s2 + 1] + bv), P::pack2(c[4 * s2 + 2] + bv, c[4 * s2 + 3] + bv),
-                    P::pack2(c[4 * (s2 + 2) + 0] + bv, c[4 * (s2 + 2) + 1] + bv), P::pack2(c[4 * (s2 + 2) + 2] + bv, c[4 * (s2 + 2) + 3] + bv)};
+                    P::pack2(c[4 * s2 + 0], c[4 * s2 + 1]), P::pack2(c[4 * s2 + 2], c[4 * s2 + 3]),
+                    P::pack2(c[4 * (s2 + 2) + 0], c[4 * (s2 + 2) + 1]), P::pack2(c[4 * (s2 + 2) + 2], c[4 * (s2 + 2) + 3])};
             } else if (vcol[t][s2] >= 0) {    // (half s2 of the block: tokens 16 s2 .., registers q = 2 s2, 2 s2 + 1)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int q = 2 * s2 + e;
                     *reinterpret_cast<uint2*>(rowp + (size_t)(vcol[t][s2] + 8 * (2 * e + hh)) * 2) = make_uint2(
-                        P::pack2(c[4 * q + 0] + bv, c[4 * q + 1] + bv), P::pack2(c[4 * q + 2] + bv, c[4 * q + 3] + bv));
+                        P::pack2(c[4 * q + 0], c[4 * q + 1]), P::pack2(c[4 * q + 2], c[4 * q + 3]));
                 }
             }
         }
     };
-    float4 b4[4] = {};
     auto half_step = [&](auto hs_tag, u32x4 (&cur)[16], u32x4 (&nxt)[16]) {
         constexpr int HS = decltype(hs_tag)::value;
         constexpr int STEP = HS / KH, kh = HS % KH;
         constexpr bool SWAP = STEP / RB == 2;
         constexpr bool LAST = HS + 1 == NHS;
-        constexpr bool EPI = kh == 0 && STEP > 0;            // the previous step's epilogue rides along
+        constexpr bool EPI = kh == 0 && STEP > STEP0;        // the previous step's epilogue rides along
         const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
-#ifdef PPG_TAIL_BIAS_IN_UNIT
-        if constexpr (EPI) {
-            // (LDS reads by compiler code: waited for HERE, not in the middle of the stream where the compiler's
-            // lgkmcnt(0) would drain the fragment ring)
-            bias_of(std::integral_constant<int, STEP - 1>{}, b4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(b4[q].x), "+v"(b4[q].y), "+v"(b4[q].z), "+v"(b4[q].w));
-        }
-#endif
         // this step's bias: the C operand of its first MFMAs (LDS reads by compiler code, waited for HERE)
         f32x16 cinit = zero;
         if constexpr (kh == 0) {
@@ -383,7 +369,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             // the next half-step's fragments first, the previous step's stores behind them
             if constexpr (!LAST && i < 16) gload_frag<i>(nxt[i], voff, nbase);
             if constexpr (EPI && i >= 16 && (i - 16) % USTRIDE == 0 && (i - 16) / USTRIDE < NU)
-                unit(std::integral_constant<int, STEP - 1>{}, std::integral_constant<int, (i - 16) / USTRIDE>{}, b4);
+                unit(std::integral_constant<int, STEP - 1>{}, std::integral_constant<int, (i - 16) / USTRIDE>{});
         });
         // the fragments have landed (registers an asm load writes must be waited for before compiler code may touch them)
         if constexpr (!LAST) {
@@ -398,18 +384,15 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // (half-step 0's fragments arrived in set 1 with the last FFN chunk)
+    // (the first half-step's fragments arrived in set 1 with the last FFN chunk)
     [&]<int... S>(std::integer_sequence<int, S...>) {
-        ((S % 2 == 0 ? half_step(std::integral_constant<int, S>{}, w1f, w2f)
-                     : half_step(std::integral_constant<int, S>{}, w2f, w1f)), ...);
-    }(std::make_integer_sequence<int, NHS>{});
+        (((HS0 + S) % 2 == 0 ? half_step(std::integral_constant<int, HS0 + S>{}, w1f, w2f)
+                             : half_step(std::integral_constant<int, HS0 + S>{}, w2f, w1f)), ...);
+    }(std::make_integer_sequence<int, NHS - HS0>{});
     // the last step's epilogue
-#ifdef PPG_TAIL_BIAS_IN_UNIT
-    bias_of(std::integral_constant<int, NSTEP - 1>{}, b4);
-#endif
     (void)TOKS;
     [&]<int... U>(std::integer_sequence<int, U...>) {
-        (unit(std::integral_constant<int, NSTEP - 1>{}, std::integral_constant<int, U>{}, b4), ...);
+        (unit(std::integral_constant<int, NSTEP - 1>{}, std::integral_constant<int, U>{}), ...);
     }(std::make_integer_sequence<int, NU>{});
 }
 

@@ -30,25 +30,10 @@
 // accumulator of one GEMM is the operand of the next after ONE ds_write_b128.
 #include "ppg_layer32.h"
 
-// phase A of the hidden-256 chunk loop: h in architectural registers (inline-asm MFMAs), or -- -DPPG_L32_H_IN_ACC, the
-// form until round 5, kept for A/B builds -- wherever the compiler puts a builtin MFMA's result
-#ifdef PPG_L32_H_IN_ACC
-#define PPG_MMA_H0(d, a, b, c) (d) = P::mma32((a), (b), (c))
-#define PPG_MMA_H(d, a, b) (d) = P::mma32((a), (b), (d))
-#define PPG_W2SET w2f
-#define PPG_W2LOAD gload_frag
-#define PPG_W2PIN "+v"
-#else
-#define PPG_MMA_H0(d, a, b, c) P::mma32v0((d), (a), (b), (c))
-#define PPG_MMA_H(d, a, b) P::mma32v((d), (a), (b))
-#define PPG_W2SET w2a
-#define PPG_W2LOAD gload_frag_acc
-#define PPG_W2PIN "+a"
-#endif
-
 namespace {
 
-template <class P, int HIDT, bool QKV, int TBS = tile_blocks(HIDT)>
+// QKV: 0 no tail, 1 the next layer's Q | K | V, 2 its K | V only (see qkv_tail)
+template <class P, int HIDT, int QKV, int TBS = tile_blocks(HIDT)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void layer32_kernel(Layer32Args a) {
     using G = Geo<HIDT, TBS>;
     constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
@@ -78,6 +63,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* lnp2 = reinterpret_cast<float*>(smem + G::L_LNP2);
     float* stats = reinterpret_cast<float*>(smem + G::L_STATS);
     const int fbase = 32 * RB * wave;               // first feature of this wave
+    // the W_qkv fragments of the tail's first half-step (they travel into set 1 under the last FFN chunk)
+    constexpr int KIND0 = QKV == 2 ? 1 : 0;
+    [[maybe_unused]] const char* wq_first = a.wq_img + ((size_t)wave * 3 * RB * KS + 16 * qkv_first_half_step<HIDT, KIND0>()) * 1024;
 
 #ifdef PPG_FFN_TIMING
     auto pstamp = [&](int k) {
@@ -227,14 +215,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if constexpr (XPRE) rv = res[(t * RB + rb) * 2 + s2];          // (requested at the top of the kernel)
                         else rv = *reinterpret_cast<const u32x4*>(xh + ((gblock(t) * RB + rb) * 2 + s2) * 1024);
                         w4[0] = rv.x; w4[1] = rv.y; w4[2] = rv.z; w4[3] = rv.w;
-#ifdef PPG_L32_LN_OLD
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f16x2 pr = __builtin_bit_cast(f16x2, w4[j]);
-                            r8[2 * j] = (float)pr[0];
-                            r8[2 * j + 1] = (float)pr[1];
-                        }
-#endif
                     } else if constexpr (RES) {         // X32 order: one contiguous KiB per load instruction
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
@@ -247,7 +227,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const int q = 2 * s2 + e;
                         float4 bv;
                         if constexpr (KEEP) bv = bias4[rb][q]; else bv = quad(0, rb, q);
-#ifndef PPG_L32_LN_OLD
                         if constexpr (RES && XH) {
                             // acc + bias + fp16 residual: the conversion rides in the add (v_fma_mix_f32: src0 an fp16 half
                             // selected by op_sel, times 1.0, plus an fp32)
@@ -261,7 +240,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                 yacc[rb][t][4 * q + k] = out;
                             }
                         } else
-#endif
                         {
                         yacc[rb][t][4 * q + 0] += bv.x + r8[4 * e + 0]; yacc[rb][t][4 * q + 1] += bv.y + r8[4 * e + 1];
                         yacc[rb][t][4 * q + 2] += bv.z + r8[4 * e + 2]; yacc[rb][t][4 * q + 3] += bv.w + r8[4 * e + 3];
@@ -290,13 +268,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float* s = stats + 32 * t + tok;
             const float mean = ((s[0] + s[TOKS]) + (s[2 * TOKS] + s[3 * TOKS])) * (1.0f / HIDT);
             const float ex2 = ((s[4 * TOKS] + s[5 * TOKS]) + (s[6 * TOKS] + s[7 * TOKS])) * (1.0f / HIDT);
-#ifdef PPG_L32_LN_OLD
-            const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + kLnEps32);
-#else
             // (v_rsq_f32, 1 ulp: the IEEE division and square root are ~30 instructions per token block of a phase
             // in which the matrix pipe idles)
             const float rstd = __builtin_amdgcn_rsqf(fmaxf(ex2 - mean * mean, 0.f) + kLnEps32);
-#endif
             const float shift = -mean * rstd;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -409,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             u32x4 (&w2n)[16] = *(PAR ? &w2f : &w2g);                  // free: W2 of chunk c + 1 goes here
             // W1 of chunk c + 2; behind the last chunks the first half-step of the Q/K/V tail, which expects it in set 0
             // (parity 0 is the second to last chunk: NCH is even); anything else harmless
-            const char* nx = c + 2 < NCH ? w1_of(c + 2) : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1_of(c));
+            const char* nx = c + 2 < NCH ? w1_of(c + 2) : (QKV ? wq_first : w1_of(c));
             const char* nx2 = w2_of(c + 1 < NCH ? c + 1 : c);
             const int cb = c + 2 < NCH ? c + 2 : c;
             f32x16 bias;
@@ -493,17 +467,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             cstamp(0);
             const f32x16 bias = bias_of(braw);
             vm_wait_all(w1f);
-#ifdef PPG_L32_HOTW
-            // (experiment: every chunk reads chunk 0's weights -- wrong results, the weights always hot in L2)
-            const char* w2c = a.w2_img + (((size_t)0 * 4 + wave) * RB * 8) * 1024;
-            const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)0 * 4 + wave) * KS) * 1024
-#else
             const char* w2c = a.w2_img + (((size_t)c * 4 + wave) * RB * 8) * 1024;      // this chunk's W2 fragments [rb][ks8]
             // what goes into the W1 register set during phase B: the next chunk's fragments; after the last chunk the
             // first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
             const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
-#endif
-                                : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024);
+                                : (QKV ? wq_first : a.w1_img + (((size_t)c * 4 + wave) * KS) * 1024);
             const int cn = c + 1 < NCH ? c + 1 : c;
             f32x16 hacc[TB];
             // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
@@ -532,26 +500,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < 48) {
                     constexpr int ks = i / 3, tb = i % 3;
-                    if constexpr (ks == 0) PPG_MMA_H0(hacc[tb], w1f[0], bf, bias);
-                    else PPG_MMA_H(hacc[tb], w1f[ks], bf);
-                    if constexpr (i % 3 == 1) PPG_W2LOAD<i / 3>(PPG_W2SET[i / 3], voff, w2c);
+                    if constexpr (ks == 0) P::mma32v0(hacc[tb], w1f[0], bf, bias);
+                    else P::mma32v(hacc[tb], w1f[ks], bf);
+                    if constexpr (i % 3 == 1) gload_frag_acc<i / 3>(w2a[i / 3], voff, w2c);
                 } else if constexpr (i < 80) {
                     constexpr int j = i - 48, ks = j / 2, tb = 3 + j % 2;
                     if constexpr (j == 0) cstamp(1);
-                    if constexpr (ks == 0) PPG_MMA_H0(hacc[tb], w1f[0], bf, bias);
-                    else PPG_MMA_H(hacc[tb], w1f[ks], bf);
+                    if constexpr (ks == 0) P::mma32v0(hacc[tb], w1f[0], bf, bias);
+                    else P::mma32v(hacc[tb], w1f[ks], bf);
                     // (b1 is the C operand of step 49's MFMA, which reads it over its passes: the registers stay b1's until
                     // that MFMA is done -- the compiler, blind to the asm, handed them to the next instruction otherwise)
                     if constexpr (j == 4) asm volatile("" :: "v"(bias));
-#ifdef PPG_L32_UNITS_OLD
-                    if constexpr (j % 3 == 2 && j / 3 < 6) h_write(std::integral_constant<int, (j / 3) / 2>{}, std::integral_constant<int, (j / 3) % 2>{});
-#else
                     // unit k = (block k / 2, half k % 2) as two half-units on the steps j = 3 k + 2, 3 k + 3.  The last write is at
                     // j = 18 (step 66): a wave's LDS operations complete in order, and by barrier X (step 74) it has waited for the
                     // ring read it issued behind that write (step 66's, awaited at step 72).
                     if constexpr (j >= 2 && (j - 2) % 3 < 2 && (j - 2) / 3 < 6)
                         h_half(std::integral_constant<int, ((j - 2) / 3) / 2>{}, std::integral_constant<int, ((j - 2) / 3) % 2>{}, std::integral_constant<int, (j - 2) % 3>{});
-#endif
                     if constexpr (i == 74) asm volatile("s_barrier" ::: "memory");
                 } else if constexpr (i < 104) {
                     constexpr int j = i - 80, ks = j / 3, tb = j % 3;
@@ -559,26 +523,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         cstamp(2);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this chunk's W2 fragments have landed
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) asm volatile("" : PPG_W2PIN(PPG_W2SET[k]));
+                        for (int k = 0; k < 16; ++k) asm volatile("" : "+a"(w2a[k]));
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    yacc[0][tb] = P::mma32(PPG_W2SET[ks], bf, yacc[0][tb]);
-                    yacc[1][tb] = P::mma32(PPG_W2SET[8 + ks], bf, yacc[1][tb]);
+                    yacc[0][tb] = P::mma32(w2a[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(w2a[8 + ks], bf, yacc[1][tb]);
                     if constexpr (j < 16) gload_frag<j>(w1f[j], voff, next1);
-#ifdef PPG_L32_UNITS_OLD
-                    if constexpr (j % 2 == 1 && j / 2 < 4) h_write(std::integral_constant<int, 3 + (j / 2) / 2>{}, std::integral_constant<int, (j / 2) % 2>{});
-#else
                     // the four units of blocks 3, 4 on the steps j = 1, 4, 7, 10 (two MFMAs each: a unit fits).  The last write
                     // is at step 90; barrier Y (step 98) comes behind the wait for step 90's ring read (awaited at step 96).
                     if constexpr (j % 3 == 1 && j / 3 < 4) h_write(std::integral_constant<int, 3 + (j / 3) / 2>{}, std::integral_constant<int, (j / 3) % 2>{});
-#endif
                     if constexpr (j == 17) bias_read(braw, cn);
                     if constexpr (i == 98) asm volatile("s_barrier" ::: "memory");
                 } else {
                     constexpr int j = i - 104, ks = j / 2, tb = 3 + j % 2;
                     if constexpr (j == 0) cstamp(3);
-                    yacc[0][tb] = P::mma32(PPG_W2SET[ks], bf, yacc[0][tb]);
-                    yacc[1][tb] = P::mma32(PPG_W2SET[8 + ks], bf, yacc[1][tb]);
+                    yacc[0][tb] = P::mma32(w2a[ks], bf, yacc[0][tb]);
+                    yacc[1][tb] = P::mma32(w2a[8 + ks], bf, yacc[1][tb]);
                 }
             });
             cstamp(5);
@@ -610,7 +570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // what goes into the W1 register set after this chunk: the next chunk's first 16 fragments; after the
             // last chunk the first half-step of the Q/K/V tail (or, without a tail, this chunk's again: harmless)
             const char* next1 = c + 1 < NCH ? a.w1_img + (((size_t)(c + 1) * 4 + wave) * KS) * 1024
-                                : (QKV ? a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024 : w1c);
+                                : (QKV ? wq_first : w1c);
             f32x16 hacc[TB];
             // ReLU + pack of one finished block: the accumulator IS the next GEMM's B fragment layout
             auto h_write = [&](auto t_tag, auto s_tag) {
@@ -696,7 +656,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(5);
 
     if constexpr (QKV) {
-        qkv_tail<P, HIDT, TBS>(a, smem, m0, w1f, w2f, nblk);
+        qkv_tail<P, HIDT, TBS, KIND0>(a, smem, m0, w1f, w2f, nblk);
         pstamp(6);
     }
 }
@@ -718,12 +678,16 @@ hipError_t launch_layer32_h(const Layer32Args& a, hipStream_t s) {
     if constexpr (HIDT == 256) {
         if (a.sub_tiles) {                 // two token blocks per workgroup, 3 workgroups per 160-token tile
             if ((a.F / HC) % 2) return hipErrorInvalidValue;
-            if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true, 2>, Geo<HIDT, 2>{}, 3);
-            return launch(layer32_kernel<P, HIDT, false, 2>, Geo<HIDT, 2>{}, 3);
+            if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, 1, 2>, Geo<HIDT, 2>{}, 3);
+            return launch(layer32_kernel<P, HIDT, 0, 2>, Geo<HIDT, 2>{}, 3);
         }
     }
-    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true>, Geo<HIDT>{}, 1);
-    return launch(layer32_kernel<P, HIDT, false>, Geo<HIDT>{}, 1);
+    if constexpr (HIDT == 256) {
+        if (a.wq_img != nullptr && a.kv_only) return launch(layer32_kernel<P, HIDT, 2>, Geo<HIDT>{}, 1);
+    }
+    if (a.kv_only) return hipErrorInvalidValue;      // (whole tiles at hidden 256 only)
+    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, 1>, Geo<HIDT>{}, 1);
+    return launch(layer32_kernel<P, HIDT, 0>, Geo<HIDT>{}, 1);
 }
 
 template <class P>

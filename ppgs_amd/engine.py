@@ -405,7 +405,9 @@ class Engine:
             else:
                 workspace = self._workspaces.get(stream)
                 if workspace is None or workspace.numel() < size.value:
-                    workspace = torch.empty(
+                    # (zeros: nothing reads a byte it has not written -- test_poisoned_workspace -- but a grow-only
+                    # buffer allocated once may as well start defined)
+                    workspace = torch.zeros(
                         max(size.value, 256), dtype=torch.uint8, device=self.device)
                     # a buffer allocated under stream capture lives in the graph's
                     # private pool: never cache it for later eager calls

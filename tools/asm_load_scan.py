@@ -7,6 +7,10 @@ matches (default: head32_kernel) in program order, keeps the vector-memory event
 `s_waitcnt vmcnt(N)` retires all but the N youngest) and reports every instruction that names a register a
 `global_load_dwordx4 v|a[..], v, s[..]` still in flight is going to write.
 
+Control flow: the walk is linear.  Behind an unconditional forward `s_branch` the walk continues with nothing in flight
+(the code there is reached from elsewhere, in a state the walk does not know) and picks the state at the branch up
+again at its target.
+
     python tools/asm_load_scan.py [library.so] [kernel-name-substring]      exit 1 if anything is reported
 """
 import os
@@ -51,15 +55,25 @@ def scan(path, want):
     bad, seen, tracked = [], 0, 0
     for listing in listings(path):
         name, inflight, done = None, [], True
+        resume = {}                                             # branch target address -> the state at the branch
         for line in listing.splitlines():
             m = re.match(r'^[0-9a-f]+ <(.*)>:$', line)
             if m:
-                name, inflight, done = m.group(1), [], want not in m.group(1)
+                name, inflight, done, resume = m.group(1), [], want not in m.group(1), {}
                 seen += not done
                 continue
             if done or name is None:
                 continue
             text = line.split('//')[0]
+            am = re.search(r'//\s*([0-9A-Fa-f]+):', line)
+            addr = int(am.group(1), 16) if am else None
+            if addr is not None and addr in resume:
+                inflight = resume.pop(addr) + [e for e in inflight if e]
+            b = re.match(r'^\s*s_branch\s+(\d+)', text)
+            if b and addr is not None and int(b.group(1)) < 32768:
+                resume[addr + 4 + 4 * int(b.group(1))] = inflight
+                inflight = []
+                continue
             w = re.search(r's_waitcnt\s+.*vmcnt\((\d+)\)', text)
             if w:
                 keep = int(w.group(1))

@@ -1,4 +1,5 @@
-"""Phase stamps of the head kernel at 32 x 1000 frames (PPGS_AMD_H32_TIMING=1 python tools/head_phases.py [precision]):
+"""Phase stamps of the head kernel at 32 x 1000 frames, from a timing build (make VARIANT=timing EXTRA=-DPPG_H32_TIMING;
+PPGS_AMD_LIB=ppgs_amd/libppgs_amd_timing.so PPGS_AMD_H32_TIMING=1 python tools/head_phases.py [precision]):
 the engine prints workgroup 0's s_memtime differences per wave when it is destroyed."""
 import os
 import sys

@@ -2,7 +2,6 @@
 # Builds the forensics artefacts of DESIGN 4.4 into tools/bin/ (git-ignored, shipped to the GPU box by gpurun):
 #   libaggressors.so                 synthetic aggressor / victim kernels (tools/probes/aggressors.hip)
 #   mfma_clock_probe                 dense-MFMA clock / delivered-peak probe (tools/probes/mfma_clock_probe.hip; bench.py reports it)
-#   libattn64_probe.so               test-only entry to ppg_attn64.hip's launcher (tools/probes/attn64_probe.hip)
 #   libppgs_amd_<variant>.so         the product library with ONLY ppg_frontend.hip rebuilt with other flags
 # usage: tools/probes/build.sh [variant "flags" ...]      e.g.  r2 "-DPPG_FE_R2"  r2_O1 "-DPPG_FE_R2 -O1"
 set -e
@@ -12,7 +11,6 @@ BIN=$ROOT/tools/bin
 mkdir -p "$BIN"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -Wno-inline-asm -o "$BIN/libaggressors.so" "$ROOT/tools/probes/aggressors.hip"
-$HIPCC --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -Wno-inline-asm -Wno-unused-function -I"$ROOT/include" -o "$BIN/libattn64_probe.so" "$ROOT/tools/probes/attn64_probe.hip"
 $HIPCC --offload-arch=gfx950 -O3 -std=c++20 -Wno-unused-result -o "$BIN/mfma_clock_probe" "$ROOT/tools/probes/mfma_clock_probe.hip"
 make -C "$CSRC" -j8 >/dev/null
 while [ $# -ge 2 ]; do
