@@ -68,6 +68,10 @@ EVENT_STRIDE = 6               # roofline leg: HIP events around every 6th layer
 PEAK_16BIT_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
 PEAK_FP32_TFLOPS = 157.3
 HIDDEN, FFN, LAYERS = 256, 2048, 5
+# where a rank's tensors live.  'cuda' always; tests/test_dist_gloo.py sets 'cpu' to walk rank_main's N-rank
+# bookkeeping (sharding, barriers, the gatherv, the record's fields) over gloo with a stub engine -- no such record is a
+# measurement, and the engine itself has no CPU path
+DEVICE = 'cuda'
 
 
 # PPGS_AMD_* switches that select a CONFIGURATION of the same computed work (recorded in the line as `env_switches`);
@@ -311,7 +315,7 @@ def pmc_traffic(kernels, prefix):
     step) is the one the roofline line describes."""
     import re
     names = [k for k in kernels if k.startswith(prefix)]
-    tail = [k for k in names if re.search(r', true\b|Lb1', k)]
+    tail = [k for k in names if re.search(r', true\b|Lb1|layer32_kernel<[^,]*, \d+, [12],', k)]
     for name in tail or names:
         entry = kernels[name]
         if 'FETCH_SIZE' in entry and 'WRITE_SIZE' in entry:
@@ -334,16 +338,20 @@ def pmc_mfma_busy(kernels):
 ###############################################################################
 
 
-def layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer):
-    """Algorithmic FLOPs per processed frame of one layer-kernel launch (SURVEY.md
-    8(d)): FFN 4*H*F; + the out-projection 2*H*H when it is fused into the
-    kernel (no separate out-proj launch shows up); + the NEXT layer's Q/K/V
-    projection 6*H*H for all launches but the last layer's (mean over the 5)."""
+def layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer, kv_only_tail=False):
+    """Algorithmic FLOPs per processed frame of one layer-kernel launch, the MEAN over a step's LAYERS launches (the
+    roofline leg's events rotate through them): FFN 4*H*F; + the out-projection 2*H*H when it is fused
+    into the kernel (no separate out-proj launch shows up); + the NEXT layer's Q/K/V projection 6*H*H for the launches
+    that compute it -- never the last layer's, and one launch fewer when the head kernel makes layer 0's Q/K/V (no
+    gather launch shows up) and no stand-alone Q/K/V launch exists: 4 of the 5.  `kv_only_tail`: the tails compute K | V
+    only (4*H*H; the Q rows are made by the attention workgroups, whose launches are not this kernel)."""
     op_fused = kernels['outproj_ln'][1] == 0
-    qkv_own = kernels['qkv'][1] / breakdown_steps / launches_per_layer
-    qkv_fused_layers = max(LAYERS - qkv_own, 0.0) if op_fused else 0.0
+    qkv_own = kernels['qkv'][1] / breakdown_steps / launches_per_layer      # stand-alone Q/K/V launches per step and pipeline
+    head_fused = 1 if kernels['gather'][1] == 0 else 0                       # layer 0's Q/K/V inside the head kernel
+    qkv_fused_layers = max(min(LAYERS - qkv_own - head_fused, LAYERS - 1), 0.0) if op_fused else 0.0
+    tail = (4.0 if kv_only_tail else 6.0) * HIDDEN * HIDDEN
     return (4.0 * HIDDEN * FFN + (2.0 * HIDDEN * HIDDEN if op_fused else 0.0)
-            + 6.0 * HIDDEN * HIDDEN * qkv_fused_layers / LAYERS), op_fused, qkv_fused_layers
+            + tail * qkv_fused_layers / LAYERS), op_fused, qkv_fused_layers
 
 
 def run_c2(args, rank, world, local_rank, use_dist):
@@ -563,16 +571,19 @@ def run_c2(args, rank, world, local_rank, use_dist):
     step_flops = BATCH * data.flops(FRAMES)
     # CUs a launch of the dominant kernel can occupy: one workgroup per CU (its LDS tile), one workgroup per token tile
     launch_workgroups = None
-    if args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0':
-        launch_workgroups = -(-info.tokens // 160) // launches_per_layer
+    x2 = args.precision == 'fp16x2'                     # ffn32x2_kernel: 96-token tiles
+    layer32 = args.precision in ('bf16', 'fp16') and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
+    if layer32 or x2:
+        launch_workgroups = -(-info.tokens // (96 if x2 else 160)) // launches_per_layer
     cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
     launch_cus = min(launch_workgroups, cus) if launch_workgroups else cus
     launch_peak = peak * launch_cus / cus
-    layer32 = args.precision != 'fp32' and os.environ.get('PPGS_AMD_LAYER32', '1') != '0'
-    pmc, pmc_from = pmc_summary('_fp16x2' if args.precision == 'fp16x2' else '', args.precision)
-    traffic = pmc_traffic(pmc, 'layer32_' if layer32 else 'ffn_') if pmc else None
+    pmc, pmc_from = pmc_summary('_fp16x2' if x2 else '', args.precision)
+    traffic = pmc_traffic(pmc, 'ffn32x2_' if x2 else ('layer32_' if layer32 else 'ffn_')) if pmc else None
     mfma_busy = pmc_mfma_busy(pmc) if pmc else None
-    kernel_name = ('layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
+    kernel_name = ('ffn32x2_kernel (feature-split layer kernel on fp16 hi + lo operand pairs, three v_mfma_f32_32x32x16_f16 '
+                   'per product: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2, next layer Q/K/V)') if x2 else (
+                   'layer32_kernel (feature-split layer kernel on v_mfma_f32_32x32x16: out-proj+residual+LN1, '
                    'W1+ReLU+W2+residual+LN2' + (', next layer Q/K/V)' if qkv_fused_layers else ')')) if layer32 else (
         'ffn_mixed_kernel (token-split layer kernel: out-proj+residual+LN1, W1+ReLU+W2+residual+LN2'
         + (', next layer Q/K/V)' if qkv_fused_layers else ')') if op_fused
@@ -690,11 +701,11 @@ def run_c4(args, rank, world, local_rank, use_dist):
     # (row budget: no batch is one tile more than a whole round of the layer kernel's workgroups)
     batches = data.pack_batches([frames[i] for i in mine], 32000, max_rows=data.row_budget(32000, gpu=local_rank))
     # this rank's padded batches, generated on its own GPU (nobody else ever holds them)
-    device_generator = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    device_generator = torch.Generator(device=DEVICE).manual_seed(1234 + rank)
     padded = []
     for batch in batches:
         longest = max(frames[mine[j]] for j in batch) * config.HOPSIZE
-        block = 0.1 * torch.randn((len(batch), 1, longest), device='cuda', generator=device_generator)
+        block = 0.1 * torch.randn((len(batch), 1, longest), device=DEVICE, generator=device_generator)
         for row, j in enumerate(batch):
             block[row, :, frames[mine[j]] * config.HOPSIZE:] = 0.
         padded.append(block)
@@ -734,7 +745,7 @@ def run_c4(args, rank, world, local_rank, use_dist):
         elapsed = float(worst.item())
     # the only collective of the path: gatherv of the posteriors to rank 0
     outs = one_pass(keep=True)
-    local = torch.cat(outs, dim=0) if outs else torch.zeros((0, 40), device='cuda')
+    local = torch.cat(outs, dim=0) if outs else torch.zeros((0, 40), device=DEVICE)
     order = [mine[j] for batch in batches for j in batch]
     barrier()
     start = time.perf_counter()

@@ -685,7 +685,7 @@ hipError_t launch_layer32_h(const Layer32Args& a, hipStream_t s) {
     if constexpr (HIDT == 256) {
         if (a.wq_img != nullptr && a.kv_only) return launch(layer32_kernel<P, HIDT, 2>, Geo<HIDT>{}, 1);
     }
-    if (a.kv_only) return hipErrorInvalidValue;      // (whole tiles at hidden 256 only)
+    if (a.wq_img != nullptr && a.kv_only) return hipErrorInvalidValue;      // (whole tiles at hidden 256 only)
     if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, 1>, Geo<HIDT>{}, 1);
     return launch(layer32_kernel<P, HIDT, 0>, Geo<HIDT>{}, 1);
 }

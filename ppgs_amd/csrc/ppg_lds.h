@@ -4,6 +4,8 @@
 
 #include "ppg_device.h"
 
+#include <type_traits>
+
 namespace {
 
 // XOR swizzle of a 16-byte slot index inside an LDS tile row; conflict-free
@@ -132,5 +134,57 @@ struct FragLayout {
         for (int j = 0; j < VAR; ++j) fb[j] = tile + base(idx, g, j);
     }
 };
+
+// Software-pipelined LDS fragment stream for one wave per SIMD: D reads are
+// kept in flight; fragment I is consumed (its MFMAs issued) and its ring slot
+// immediately re-armed with fragment I + D.
+template <class L, int I, int R, int D, class USE>
+__device__ __forceinline__ void lds_stream_step(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR], USE& use) {
+    if constexpr (I < R) {
+        lgkm_wait<(R - 1 - I < D - 1) ? (R - 1 - I) : (D - 1)>(ring[I % D]);
+        use(std::integral_constant<int, I>{}, ring[I % D]);
+        if constexpr (I + D < R) ds_read_b128_asm<L::imm(I + D)>(ring[I % D], fb[L::variant(I + D)]);
+        lds_stream_step<L, I + 1, R, D>(ring, fb, use);
+    }
+}
+template <class L, int I, int R, int D>
+__device__ __forceinline__ void lds_stream_prime(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR]) {
+    if constexpr (I < D && I < R) {
+        ds_read_b128_asm<L::imm(I)>(ring[I], fb[L::variant(I)]);
+        lds_stream_prime<L, I + 1, R, D>(ring, fb);
+    }
+}
+// Stream over the NBLK fragments of one K-group kg (runtime-free: kg is a
+// constant after unrolling at the call site) of a FragLayout<ROW, NBLK> tile.
+template <class L, int KG, int I, int NBLK, int D, class USE>
+__device__ __forceinline__ void lds_group_step(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR], USE& use) {
+    if constexpr (I < NBLK) {
+        lgkm_wait<(NBLK - 1 - I < D - 1) ? (NBLK - 1 - I) : (D - 1)>(ring[I % D]);
+        use(std::integral_constant<int, I>{}, ring[I % D]);
+        if constexpr (I + D < NBLK) ds_read_b128_asm<L::imm(KG * NBLK + I + D)>(ring[I % D], fb[L::variant(KG * NBLK + I + D)]);
+        lds_group_step<L, KG, I + 1, NBLK, D>(ring, fb, use);
+    }
+}
+template <class L, int KG, int I, int NBLK, int D>
+__device__ __forceinline__ void lds_group_prime(u32x4 (&ring)[D], const uint32_t (&fb)[L::VAR]) {
+    if constexpr (I < D && I < NBLK) {
+        ds_read_b128_asm<L::imm(KG * NBLK + I)>(ring[I], fb[L::variant(KG * NBLK + I)]);
+        lds_group_prime<L, KG, I + 1, NBLK, D>(ring, fb);
+    }
+}
+template <class L, int NBLK, int D, class USE>
+__device__ __forceinline__ void lds_stream_group(const uint32_t (&fb)[L::VAR], int kg, USE use) {
+    u32x4 ring[D];
+    // kg is 0 or 1 at every call site (fully unrolled loops)
+    if (kg == 0) { lds_group_prime<L, 0, 0, NBLK, D>(ring, fb); lds_group_step<L, 0, 0, NBLK, D>(ring, fb, use); }
+    else         { lds_group_prime<L, 1, 0, NBLK, D>(ring, fb); lds_group_step<L, 1, 0, NBLK, D>(ring, fb, use); }
+}
+
+template <class L, int R, int D, class USE>
+__device__ __forceinline__ void lds_stream(const uint32_t (&fb)[L::VAR], USE use) {
+    u32x4 ring[D];
+    lds_stream_prime<L, 0, R, D>(ring, fb);
+    lds_stream_step<L, 0, R, D>(ring, fb, use);
+}
 
 }  // namespace

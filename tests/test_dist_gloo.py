@@ -168,3 +168,73 @@ def test_four_ranks_with_an_empty_shard(tmp_path):
         ref = ppg_oracle.from_audio(state, audios[index][None])[0]
         assert got['out'][index].shape == (40, n)
         assert np.abs(got['out'][index].numpy() - ref[:, :n].numpy()).max() < 1e-6
+
+
+# ---- bench.py's own N-rank path: rank_main for `--gpus 2 --workload c4`, end to end over gloo ----
+
+class _StubEngine:
+    """Stands in for ppgs_amd.engine.Engine (which has no CPU path): uniform posteriors of the right shape.  What the
+    test walks is bench.py's bookkeeping around it, not arithmetic."""
+
+    def __init__(self, state, device, precision):
+        self.launches = 0
+
+    def encode(self, mel, lengths):
+        self.launches += 5
+        return torch.full((mel.shape[0], 40, mel.shape[2]), 1.0 / 40)
+
+    def profile(self, on, classes=None, stride=1):
+        self.launches = 0
+
+    def profile_read(self):
+        return {'ffn': (0.05 * self.launches, self.launches)}
+
+    def pipelines(self, tokens):
+        return 1
+
+
+def _bench_rank(rank, port, world, out_path):
+    import argparse
+    import contextlib
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), PPGS_BENCH_BACKEND='gloo')
+    torch.set_num_threads(1)
+    bench = importlib.import_module('bench')
+    import ppgs_amd
+    from ppgs_amd import engine as E
+    # no GPU here: the device calls rank_main makes are no-ops, the tensors live on the CPU, the engine is the stub
+    bench.DEVICE = 'cpu'
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: world
+    torch.cuda.set_device = lambda device: None
+    torch.cuda.synchronize = lambda *a: None
+    ppgs_amd.data.row_budget = lambda max_frames, tile_rows=160, gpu=None: None
+    E.Engine = _StubEngine
+    ppgs_amd.preprocess.mel.from_audios = lambda audio: torch.zeros(audio.shape[0], 80, audio.shape[-1] // 160)
+    args = argparse.Namespace(gpus=world, steps=1, warmup=1, workload='c4', precision='bf16', utterances=48,
+                              env_config={}, env_ablation={}, no_cpu=True, no_alt=True)
+    if rank == 0:
+        with open(out_path, 'w') as f, contextlib.redirect_stdout(f):
+            bench.rank_main(args)
+    else:
+        bench.rank_main(args)
+
+
+def test_bench_rank_main_c4_two_ranks_over_gloo(tmp_path):
+    """The driver's first multi-GPU run must not die in bookkeeping: bench.py's rank_main, `--gpus 2 --workload c4`,
+    with a stub engine on CPU tensors over gloo -- LPT shards, per-rank batches, barriers, max-over-ranks, the gatherv to
+    rank 0 and every field of the record (`gather_ms`, `gather_bytes`, the world-size field, `rank0_cpus`)."""
+    import json
+    out = tmp_path / 'line.json'
+    mp.spawn(_bench_rank, args=(free_port(), 2, str(out)), nprocs=2, join=True)
+    line = json.loads(out.read_text().strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['gloo_world_size'] == 2 and line['scaling'] == 'strong'
+    assert line['config']['utterances'] == 48 and line['value'] > 0 and line['gather_ms'] >= 0
+    generator = torch.Generator().manual_seed(1234)
+    frames = torch.randint(50, 3001, (48,), generator=generator).tolist()
+    assert line['gather_bytes'] == sum(frames) * 40 * 4
+    assert line['roofline']['timed_launches'] > 0 and 'rank0_cpus' in line

@@ -225,7 +225,7 @@ def test_single_window_fp32(golden):
     g = golden('g2_single_window')
     engine, _ = eng()
     logits = run(engine, g['features'], g['lengths'], softmax=False)
-    assert np.abs(logits - g['logits']).max() < 1e-3
+    assert np.abs(logits - g['logits']).max() < 2e-4        # (measured <= 6e-5: the un-normalised path gets its own bound)
     assert np.all(logits[1, :, 100:] == 0) and np.all(logits[2, :, 37:] == 0)
     ppg = run(engine, g['features'], g['lengths'])
     assert np.abs(ppg - g['ppg']).max() < FP32_TOL
@@ -673,6 +673,13 @@ def test_c2_full_size_statistics(golden):
         assert np.abs(ppg[31, :, -64:].numpy() - g['ppg_item31_last64']).max() < tol
         assert np.abs(ppg.mean(-1).numpy() - g['ppg_mean']).max() < tol
         assert np.abs(ppg.amax(-1).numpy() - g['ppg_max']).max() < 2 * tol
+        if precision == 'fp32':
+            # every frame of every item: the per-item histogram of the winning phoneme, against the reference's own
+            # (G6 `argmax_hist`).  ONE frame of the 32 000 has its two best posteriors closer than 2e-4 in the
+            # reference's result (the fp32 mode is within 6e-5): at most one frame per item may change bins.
+            hist = np.stack([np.bincount(ppg[b].argmax(0).numpy(), minlength=40) for b in range(32)])
+            moved = np.abs(hist - g['argmax_hist']).sum(1)
+            assert moved.max() <= 2 and moved.sum() <= 4, moved
     # batch-composition invariance: an item computed alone (full length, so
     # no halo difference) equals its row in the batch
     engine, _ = eng()

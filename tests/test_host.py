@@ -425,3 +425,37 @@ def test_bench_refuses_experiment_switches_and_reads_the_clock_probe(monkeypatch
     assert 1.5 < probe['dense']['clock_ghz_p50'] < 2.4 and 31.5 < probe['dense']['cycles_per_mfma'] < 33.0
     assert 0.6 < probe['dense']['tflops'] / 2500.0 < 0.9
     assert probe['with_6_valu_per_mfma']['tflops'] < probe['with_3_valu_per_mfma']['tflops'] < probe['dense']['tflops']
+
+
+def test_bench_roofline_flops_follow_from_the_launches_that_compute_them():
+    """`roofline.flops_per_launch` is the MEAN over a step's five layer launches of what each
+    computes -- the last layer's launch has no Q/K/V tail, and with the head kernel making layer 0's Q/K/V only four of
+    the five launches carry one.  flops_per_launch x launches per step can never exceed the step's algorithmic FLOPs."""
+    import importlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    from ppgs_amd import data
+    H, F, L = bench.HIDDEN, bench.FFN, bench.LAYERS
+    steps = 5
+    processed = bench.BATCH * sum(data.chunk_lengths(bench.FRAMES))
+    step_flops = bench.BATCH * data.flops(bench.FRAMES)
+    for pipelines in (1, 2):
+        # the product's launch sequence: head kernel (class inconv), no gather / Q/K/V / out-projection launches
+        kernels = {'gather': (0.0, 0), 'inconv': (1.0, steps * pipelines), 'qkv': (0.0, 0), 'outproj_ln': (0.0, 0),
+                   'ffn': (1.0, L * steps * pipelines)}
+        per_frame, op_fused, fused = bench.layer_flops_per_frame(kernels, steps, pipelines)
+        assert op_fused and fused == L - 1
+        assert per_frame == 4 * H * F + 2 * H * H + 6 * H * H * (L - 1) / L
+        assert per_frame * processed * L <= step_flops
+        # ... K | V only tails (the Q rows made by the attention workgroups)
+        assert bench.layer_flops_per_frame(kernels, steps, pipelines, kv_only_tail=True)[0] == 4 * H * F + 2 * H * H + 4 * H * H * (L - 1) / L
+        # the unfused head (gather + input convolution + a stand-alone Q/K/V launch for layer 0): four tails as well
+        kernels.update(gather=(1.0, steps * pipelines), qkv=(1.0, steps * pipelines))
+        assert bench.layer_flops_per_frame(kernels, steps, pipelines)[2] == L - 1
+        # a stand-alone Q/K/V launch per layer: no tails
+        kernels['qkv'] = (1.0, L * steps * pipelines)
+        assert bench.layer_flops_per_frame(kernels, steps, pipelines)[0] == 4 * H * F + 2 * H * H
+    # every layer launch of a step, summed, stays inside the step
+    assert (4 * H * F + 2 * H * H) * processed * L + 6 * H * H * processed * (L - 1) < step_flops
