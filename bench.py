@@ -315,7 +315,7 @@ def pmc_traffic(kernels, prefix):
     step) is the one the roofline line describes."""
     import re
     names = [k for k in kernels if k.startswith(prefix)]
-    tail = [k for k in names if re.search(r', true\b|Lb1|layer32_kernel<[^,]*, \d+, [12],', k)]
+    tail = [k for k in names if re.search(r', true\b|Lb1', k)]
     for name in tail or names:
         entry = kernels[name]
         if 'FETCH_SIZE' in entry and 'WRITE_SIZE' in entry:
@@ -338,20 +338,18 @@ def pmc_mfma_busy(kernels):
 ###############################################################################
 
 
-def layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer, kv_only_tail=False):
+def layer_flops_per_frame(kernels, breakdown_steps, launches_per_layer):
     """Algorithmic FLOPs per processed frame of one layer-kernel launch, the MEAN over a step's LAYERS launches (the
     roofline leg's events rotate through them): FFN 4*H*F; + the out-projection 2*H*H when it is fused
     into the kernel (no separate out-proj launch shows up); + the NEXT layer's Q/K/V projection 6*H*H for the launches
     that compute it -- never the last layer's, and one launch fewer when the head kernel makes layer 0's Q/K/V (no
-    gather launch shows up) and no stand-alone Q/K/V launch exists: 4 of the 5.  `kv_only_tail`: the tails compute K | V
-    only (4*H*H; the Q rows are made by the attention workgroups, whose launches are not this kernel)."""
+    gather launch shows up) and no stand-alone Q/K/V launch exists: 4 of the 5."""
     op_fused = kernels['outproj_ln'][1] == 0
     qkv_own = kernels['qkv'][1] / breakdown_steps / launches_per_layer      # stand-alone Q/K/V launches per step and pipeline
     head_fused = 1 if kernels['gather'][1] == 0 else 0                       # layer 0's Q/K/V inside the head kernel
     qkv_fused_layers = max(min(LAYERS - qkv_own - head_fused, LAYERS - 1), 0.0) if op_fused else 0.0
-    tail = (4.0 if kv_only_tail else 6.0) * HIDDEN * HIDDEN
     return (4.0 * HIDDEN * FFN + (2.0 * HIDDEN * HIDDEN if op_fused else 0.0)
-            + tail * qkv_fused_layers / LAYERS), op_fused, qkv_fused_layers
+            + 6.0 * HIDDEN * HIDDEN * qkv_fused_layers / LAYERS), op_fused, qkv_fused_layers
 
 
 def run_c2(args, rank, world, local_rank, use_dist):

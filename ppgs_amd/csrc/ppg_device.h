@@ -513,7 +513,6 @@ struct Layer32Args {
     int write_x;              // 0: the fp32 result is not stored (last layer: only the 16-bit copy is read afterwards)
     int x_half;               // 1: X is the fp16 stream in X16 order (see x16_index) instead of fp32 in X32 order
     int sub_tiles;            // 1 (hidden 256, F / 128 even): workgroups of two token blocks, three per 160-token tile -- batches that cannot give every CU a tile
-    int kv_only;              // 1: the tail computes K | V only -- the attention workgroups make their own Q rows (AttnArgs::xq)
 };
 
 // One attention workgroup's work: a query tile of one window.  The window fields
@@ -624,7 +623,6 @@ struct Head32Args {
     int qk_slack_bytes;
     int x_half;               // 1: X is written as fp16 in X16 order (see x16_index)
     int sub_tiles;            // 1: workgroups of two token blocks, three per 160-token tile (see Layer32Args)
-    int kv_only;              // 1: layer 0's K | V only (see Layer32Args)
     int debug_mode;           // timing experiments (wrong results): 1 no convolution, 2 no Q/K/V, 4 no gather
     unsigned long long* dbg;  // PPGS_AMD_H32_TIMING=1: s_memtime stamps of workgroup 0, [wave][16]
 };

@@ -282,7 +282,6 @@ struct PpgEngine {
     bool split = false;      // PPG_PRECISION_FP16X2: operands as fp16 hi + lo planes in the fp32 path's byte layout (PrecX2)
     bool subtile = true;     // layer32 path, hidden 256: workgroups of two token blocks (three per 160-token tile) when whole tiles would leave two thirds of the CUs idle (PPGS_AMD_SUBTILE=0: whole tiles always)
     bool x16 = false;        // layer32 path: the residual stream between two layer kernels is stored as fp16 (X16 order) instead of fp32 -- default in the bf16 mode (PPGS_AMD_X16=0 / 1 overrides)
-    bool q_in_attn = false;  // layer32 path, fp16 residual stream (x16), whole tiles: the attention workgroups compute their Q rows themselves (AttnArgs::xq), the layer kernels' tails K | V only
     bool layer32 = true;     // feature-split 32x32x16 layer kernel where it applies (16-bit modes, hidden 256, batches that fill the chip; PPGS_AMD_LAYER32=0: token-split kernels everywhere)
     bool ffn_split = true;   // split-hidden FFN for small token counts (PPGS_AMD_FFN_SPLIT=0 disables)
     int num_streams = 2;    // pipelines (HIP streams) a batch of >= 128 x CUs token rows is split into (PPGS_AMD_STREAMS;
@@ -969,7 +968,6 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     HIP_OK(hipMemset(e->d_overflow, 0, 256));
     e->x16 = env_experiment("PPGS_AMD_X16", cfg->precision == PPG_PRECISION_BF16) != 0;
     e->outconv = env_switch("PPGS_AMD_OUTCONV", e->outconv) != 0;
-    e->q_in_attn = env_switch("PPGS_AMD_Q_IN_ATTN", e->q_in_attn) != 0;
 #ifdef PPG_DEBUG_MODES
     e->l32_debug = env_switch("PPGS_AMD_L32_DEBUG", 0);
     e->h32_debug = env_switch("PPGS_AMD_H32_DEBUG", 0);
@@ -1325,7 +1323,6 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     // sub-tile workgroups (two token blocks, three per tile) when whole tiles would leave two thirds of the CUs idle
     const bool sub32 = use32 && e->subtile && H == 256 && (F / 128) % 2 == 0 && 3 * tiles32 <= e->num_cus;
     const bool head = use32 && e->head32 && (2 * tiles32 >= e->num_cus || sub32);
-    const bool qx = use32 && head && !sub32 && e->q_in_attn && e->x16 && H == 256;     // Q rows made by the attention workgroups
     if (head) {
         Timed t(e, PPG_K_INCONV, s);
         Head32Args a{};
@@ -1339,7 +1336,6 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         a.debug_mode = e->h32_debug;
         a.x_half = e->x16;
         a.sub_tiles = sub32;
-        a.kv_only = qx;
         a.dbg = e->head_dbg;
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
@@ -1404,8 +1400,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             a.debug_mode = e->l32_debug;
             a.x_half = e->x16;
             a.sub_tiles = sub32;
-            a.kv_only = qx;
-            qkv_done = e->qkv_fused && l + 1 < c.num_layers;
+                qkv_done = e->qkv_fused && l + 1 < c.num_layers;
             a.write_x = l + 1 < c.num_layers;
             if (qkv_done) {
                 const DevLayer& nx = e->layers[l + 1];

@@ -33,7 +33,7 @@ struct OffIn {
     }
 };
 
-template <class P, int TBS, bool KVONLY = false>
+template <class P, int TBS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void head32_kernel(Head32Args a) {
     using G = Geo<HID, TBS>;
     constexpr int RB = G::RB, KS = G::KS, TB = G::TBN, TOKS = G::TOKS;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         [&]<int... K>(std::integer_sequence<int, K...>) { (gload_frag<K>(wf[K], voff, base), ...); }(std::make_integer_sequence<int, 16>{});
     };
     const char* wimg = a.win_img + ((size_t)wave * RB * KSI) * 1024;
-    const char* wq0 = a.wq_img + ((size_t)wave * 3 * RB * KS + 16 * qkv_first_half_step<HID, KVONLY ? 1 : 0>()) * 1024;
+    const char* wq0 = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
     // the convolution's first-round weight fragments travel under the gather (nothing below touches the two register
     // sets before the round's wait: tools/asm_load_scan.py checks the built code)
     load16(w1f, wimg);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Layer32Args la{};
     la.wq_img = a.wq_img; la.qk_out = a.qk_out; la.vt_out = a.vt_out; la.vt_ld = a.vt_ld;
     la.blk_win = a.blk_win; la.win = a.win; la.M = a.M; la.H = HID;
-    if (!(PPG_DBG(a) & 2)) qkv_tail<P, HID, TBS, KVONLY ? 1 : 0>(la, smem, m0, w1f, w2f, nblk);
+    if (!(PPG_DBG(a) & 2)) qkv_tail<P, HID, TBS>(la, smem, m0, w1f, w2f, nblk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pstamp(7);
 }
@@ -290,12 +290,6 @@ hipError_t launch_head32(int precision, const Head32Args& a, hipStream_t s) {
         return hipGetLastError();
     };
     constexpr int T5 = tile_blocks(HID);
-    if (a.kv_only) {       // (whole tiles only)
-        if (a.sub_tiles) return hipErrorInvalidValue;
-        if (precision == PPG_PRECISION_BF16) return launch(head32_kernel<PrecBF16, T5, true>, Geo<HID>{}, 1);
-        if (precision == PPG_PRECISION_FP16) return launch(head32_kernel<PrecF16, T5, true>, Geo<HID>{}, 1);
-        return hipErrorInvalidValue;
-    }
     if (precision == PPG_PRECISION_BF16) return a.sub_tiles ? launch(head32_kernel<PrecBF16, 2>, Geo<HID, 2>{}, 3) : launch(head32_kernel<PrecBF16, T5>, Geo<HID>{}, 1);
     if (precision == PPG_PRECISION_FP16) return a.sub_tiles ? launch(head32_kernel<PrecF16, 2>, Geo<HID, 2>{}, 3) : launch(head32_kernel<PrecF16, T5>, Geo<HID>{}, 1);
     return hipErrorInvalidValue;

@@ -193,20 +193,12 @@ __device__ __forceinline__ void panel_store(uint32_t pb0, int wave, int t, int r
 // step, on top of 1.4 - 3.2 k cycles of epilogue with the matrix pipe idle).  The count is exact only in a tile
 // whose rows all exist and whose token blocks are whole 32-token groups of V^T (`regular`: every tile of a
 // batch of 32-aligned windows); any other tile waits with vmcnt(0).
-//
-// KIND0 = 1: K and V only -- the attention workgroups compute their Q rows themselves from the fp16 residual rows
-// (X16 order: they ARE 32x32x16 B operands) and W_q (ppg_kernels.hip, attn_body's QX prologue): a third of the tail's
-// stores and MFMAs gone.  The caller then hands over the fragments of half-step qkv_first_half_step<..>() in w1f.
-template <int HIDT, int KIND0>
-constexpr int qkv_first_half_step() { return KIND0 * (HIDT / 128) * (HIDT / 256); }
-template <class P, int HIDT, int TBS = tile_blocks(HIDT), int KIND0 = 0>
+template <class P, int HIDT, int TBS = tile_blocks(HIDT)>
 __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const int m0, u32x4 (&w1f)[16], u32x4 (&w2f)[16],
                                          const int nblk = TBS) {
     using G = Geo<HIDT, TBS>;
     constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
     constexpr int NSTEP = 3 * RB, NHS = NSTEP * KH;
-    constexpr int STEP0 = KIND0 * RB, HS0 = STEP0 * KH;        // (both even: the register and accumulator sets alternate as from 0)
-    static_assert(HS0 == qkv_first_half_step<HIDT, KIND0>() && HS0 % 2 == 0 && STEP0 % 2 == 0, "tail entry");
     constexpr int NMMA = 16 * TB;                           // MFMAs (= stream steps) of a half-step
     constexpr int NU = 2 * TB;                              // epilogue units (one 16-byte store each in a regular tile)
     constexpr int USTRIDE = (NMMA - 16) / NU;
@@ -351,7 +343,7 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
         constexpr int STEP = HS / KH, kh = HS % KH;
         constexpr bool SWAP = STEP / RB == 2;
         constexpr bool LAST = HS + 1 == NHS;
-        constexpr bool EPI = kh == 0 && STEP > STEP0;        // the previous step's epilogue rides along
+        constexpr bool EPI = kh == 0 && STEP > 0;            // the previous step's epilogue rides along
         const char* nbase = wq + (size_t)(LAST ? HS : HS + 1) * 16 * 1024;
         // this step's bias: the C operand of its first MFMAs (LDS reads by compiler code, waited for HERE)
         f32x16 cinit = zero;
@@ -384,11 +376,11 @@ __device__ __forceinline__ void qkv_tail(const Layer32Args& a, char* smem, const
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // (the first half-step's fragments arrived in set 1 with the last FFN chunk)
+    // (half-step 0's fragments arrived in set 1 with the last FFN chunk)
     [&]<int... S>(std::integer_sequence<int, S...>) {
-        (((HS0 + S) % 2 == 0 ? half_step(std::integral_constant<int, HS0 + S>{}, w1f, w2f)
-                             : half_step(std::integral_constant<int, HS0 + S>{}, w2f, w1f)), ...);
-    }(std::make_integer_sequence<int, NHS - HS0>{});
+        ((S % 2 == 0 ? half_step(std::integral_constant<int, S>{}, w1f, w2f)
+                     : half_step(std::integral_constant<int, S>{}, w2f, w1f)), ...);
+    }(std::make_integer_sequence<int, NHS>{});
     // the last step's epilogue
     (void)TOKS;
     [&]<int... U>(std::integer_sequence<int, U...>) {

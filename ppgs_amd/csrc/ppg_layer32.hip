@@ -32,8 +32,7 @@
 
 namespace {
 
-// QKV: 0 no tail, 1 the next layer's Q | K | V, 2 its K | V only (see qkv_tail)
-template <class P, int HIDT, int QKV, int TBS = tile_blocks(HIDT)>
+template <class P, int HIDT, bool QKV, int TBS = tile_blocks(HIDT)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void layer32_kernel(Layer32Args a) {
     using G = Geo<HIDT, TBS>;
     constexpr int RB = G::RB, KS = G::KS, KH = G::KH, TB = G::TBN, TOKS = G::TOKS;
@@ -64,8 +63,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* stats = reinterpret_cast<float*>(smem + G::L_STATS);
     const int fbase = 32 * RB * wave;               // first feature of this wave
     // the W_qkv fragments of the tail's first half-step (they travel into set 1 under the last FFN chunk)
-    constexpr int KIND0 = QKV == 2 ? 1 : 0;
-    [[maybe_unused]] const char* wq_first = a.wq_img + ((size_t)wave * 3 * RB * KS + 16 * qkv_first_half_step<HIDT, KIND0>()) * 1024;
+    [[maybe_unused]] const char* wq_first = a.wq_img + ((size_t)wave * 3 * RB * KS) * 1024;
 
 #ifdef PPG_FFN_TIMING
     auto pstamp = [&](int k) {
@@ -656,7 +654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pstamp(5);
 
     if constexpr (QKV) {
-        qkv_tail<P, HIDT, TBS, KIND0>(a, smem, m0, w1f, w2f, nblk);
+        qkv_tail<P, HIDT, TBS>(a, smem, m0, w1f, w2f, nblk);
         pstamp(6);
     }
 }
@@ -678,16 +676,12 @@ hipError_t launch_layer32_h(const Layer32Args& a, hipStream_t s) {
     if constexpr (HIDT == 256) {
         if (a.sub_tiles) {                 // two token blocks per workgroup, 3 workgroups per 160-token tile
             if ((a.F / HC) % 2) return hipErrorInvalidValue;
-            if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, 1, 2>, Geo<HIDT, 2>{}, 3);
-            return launch(layer32_kernel<P, HIDT, 0, 2>, Geo<HIDT, 2>{}, 3);
+            if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true, 2>, Geo<HIDT, 2>{}, 3);
+            return launch(layer32_kernel<P, HIDT, false, 2>, Geo<HIDT, 2>{}, 3);
         }
     }
-    if constexpr (HIDT == 256) {
-        if (a.wq_img != nullptr && a.kv_only) return launch(layer32_kernel<P, HIDT, 2>, Geo<HIDT>{}, 1);
-    }
-    if (a.wq_img != nullptr && a.kv_only) return hipErrorInvalidValue;      // (whole tiles at hidden 256 only)
-    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, 1>, Geo<HIDT>{}, 1);
-    return launch(layer32_kernel<P, HIDT, 0>, Geo<HIDT>{}, 1);
+    if (a.wq_img != nullptr) return launch(layer32_kernel<P, HIDT, true>, Geo<HIDT>{}, 1);
+    return launch(layer32_kernel<P, HIDT, false>, Geo<HIDT>{}, 1);
 }
 
 template <class P>

@@ -352,8 +352,8 @@ def test_hot_kernels_do_not_wait_for_store_acknowledgements():
     spec.loader.exec_module(wait_scan)
     kernels = wait_scan.scan(library)
     budget = {
-        'layer32_kernel<PrecBF16, 256, 1, 5>': 4, 'layer32_kernel<PrecBF16, 256, 2, 5>': 4, 'layer32_kernel<PrecBF16, 256, 0, 5>': 0,
-        'head32_kernel<PrecBF16, 5, false>': 13, 'head32_kernel<PrecBF16, 5, true>': 13, 'attn_mixed_kernel<PrecBF16>': 3, 'outconv_kernel<PrecBF16>': 0,     # (attention: the tile loops' own end-of-iteration waits: two-stage, three-stage and its tile-0 stage)
+        'layer32_kernel<PrecBF16, 256, true, 5>': 4, 'layer32_kernel<PrecBF16, 256, false, 5>': 0,
+        'head32_kernel<PrecBF16, 5>': 13, 'attn_mixed_kernel<PrecBF16>': 3, 'outconv_kernel<PrecBF16>': 0,     # (attention: the tile loops' own end-of-iteration waits: two-stage, three-stage and its tile-0 stage)
         'gemm32_kernel<PrecBF16, 4, 0>': 0, 'gemm32_kernel<PrecBF16, 4, 1>': 0, 'gemm32_kernel<PrecBF16, 5, 3>': 0,
         'posconv_kernel<PrecBF16>': 0, 'w2v2_layernorm_kernel<PrecBF16, 768>': 0,
         'linear_kernel<PrecBF16, 1, 16, 1>': 1, 'ffn32x2_kernel<true, true>': 3,
@@ -379,16 +379,45 @@ def test_hand_placed_loads_stay_untouched_until_their_wait():
     asm_load_scan = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(asm_load_scan)
     seen, tracked, bad = asm_load_scan.scan(library, 'head32_kernel')
-    assert seen == 6 and tracked >= 6 * 100, (seen, tracked)
+    assert seen == 4 and tracked >= 4 * 100, (seen, tracked)
     assert not bad, bad[:5]
     # the attention kernels request their Q rows the same way (awaited with a counted vmcnt beside the tile DMAs); the
     # layer kernels (W2 into accumulation registers, hand-counted waits in the chunk loop and the tail), the fp16x2 layer
     # kernel and the wav2vec2 body's GEMM place theirs by hand as well
-    for family, kernels, loads in (('attn_mixed_kernel', 4, 4), ('attn_kernel', 8, 4), ('layer32_kernel', 14, 100),
+    for family, kernels, loads in (('attn_mixed_kernel', 4, 4), ('attn_kernel', 8, 4), ('layer32_kernel', 12, 100),
                                    ('ffn32x2_kernel', 3, 100), ('gemm32_kernel', 16, 100)):
         seen, tracked, bad = asm_load_scan.scan(library, family)
         assert seen == kernels and tracked >= loads * kernels, (family, seen, tracked)
         assert not bad, (family, bad[:5])
+
+
+def test_asm_mfma_results_are_read_far_enough_behind_their_mfma():
+    """the layer kernels' phase A issues its MFMAs from inline asm with the accumulator in
+    architectural registers, and hipcc's hazard recognizer does not see an MFMA inside asm -- the wait states between the
+    MFMA's write and the pack / ReLU that read it, and between an MFMA still reading its C operand (b1) and a VALU write
+    of those registers, exist only as source placement.  tools/mfma_hazard_scan.py walks the feature-split kernels of
+    the BUILT library and requires PASSES + 4 wait states in front of the first consumer (gfx940 guide: 8 passes 11) and
+    PASSES - 1 in front of a VALU overwrite of a live C operand: a compiler upgrade or a flag that lets the scheduler
+    hoist a consumer fails here, not as a silently stale h in the default bf16 / fp16 layer kernel."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    library = os.path.join(root, 'ppgs_amd', 'libppgs_amd.so')
+    if not os.path.exists(library) or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('no built library / llvm-objdump')
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    spec = importlib.util.spec_from_file_location('mfma_hazard_scan', os.path.join(root, 'tools', 'mfma_hazard_scan.py'))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    seen, audited, bad = scan.scan(library)
+    assert seen >= 30 and audited >= 500, (seen, audited)        # (the asm MFMAs of the layer kernels are there to be audited)
+    assert not bad, bad[:5]
+    # the walk has teeth: with a window of 24 more wait states it names the closest consumers (the fp16x2 kernel's)
+    scan.MARGIN = 28
+    try:
+        assert scan.scan(library)[2]
+    finally:
+        scan.MARGIN = 4
 
 
 def test_bench_refuses_experiment_switches_and_reads_the_clock_probe(monkeypatch, tmp_path):
@@ -449,8 +478,6 @@ def test_bench_roofline_flops_follow_from_the_launches_that_compute_them():
         assert op_fused and fused == L - 1
         assert per_frame == 4 * H * F + 2 * H * H + 6 * H * H * (L - 1) / L
         assert per_frame * processed * L <= step_flops
-        # ... K | V only tails (the Q rows made by the attention workgroups)
-        assert bench.layer_flops_per_frame(kernels, steps, pipelines, kv_only_tail=True)[0] == 4 * H * F + 2 * H * H + 4 * H * H * (L - 1) / L
         # the unfused head (gather + input convolution + a stand-alone Q/K/V launch for layer 0): four tails as well
         kernels.update(gather=(1.0, steps * pipelines), qkv=(1.0, steps * pipelines))
         assert bench.layer_flops_per_frame(kernels, steps, pipelines)[2] == L - 1
