@@ -337,10 +337,13 @@ __device__ __forceinline__ f32x2 gelu_erf_pair(f32x2 x) {
     g = g * z + 1.6279085932e+00f;
     const f32x2 arg = z * g;
     const f32x2 e = {__builtin_amdgcn_exp2f(-arg.x), __builtin_amdgcn_exp2f(-arg.y)};
-    // max(x, 0) as (x + |x|) / 2: fmaxf() returns its non-NaN operand, which turned GELU(NaN) and GELU(-Inf) into a
-    // finite value where torch returns NaN (-Inf + Inf = NaN here too); one add with a free |.| modifier per value
-    const f32x2 twice = {x.x + fabsf(x.x), x.y + fabsf(x.y)};
-    return __builtin_elementwise_fma(z * e, f32x2{-0.70710678118654752f, -0.70710678118654752f}, twice * 0.5f);
+    // max(x, 0) as x / 2 + |x| / 2: fmaxf() returns its non-NaN operand, which turned GELU(NaN) and GELU(-Inf) into a
+    // finite value where torch returns NaN (-Inf / 2 + Inf / 2 = NaN here too); halved BEFORE the add, so that a finite
+    // x above FLT_MAX / 2 stays finite (x + |x| overflowed there: ADVICE r5).  One multiply and one fma with a free
+    // |.| modifier per value
+    const f32x2 half = x * 0.5f;
+    const f32x2 relu = {fmaf(fabsf(x.x), 0.5f, half.x), fmaf(fabsf(x.y), 0.5f, half.y)};
+    return __builtin_elementwise_fma(z * e, f32x2{-0.70710678118654752f, -0.70710678118654752f}, relu);
 }
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fminf(fabsf(x) * 0.70710678118654752f, 4.3f);
@@ -351,7 +354,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     g = fmaf(g, z, 1.4848162721e-01f);
     g = fmaf(g, z, 9.1841639080e-01f);
     g = fmaf(g, z, 1.6279085932e+00f);
-    return fmaf(z * __builtin_amdgcn_exp2f(-(z * g)), -0.70710678118654752f, 0.5f * (x + fabsf(x)));   // (NaN / -Inf -> NaN, as torch)
+    return fmaf(z * __builtin_amdgcn_exp2f(-(z * g)), -0.70710678118654752f, fmaf(fabsf(x), 0.5f, 0.5f * x));   // (NaN / -Inf -> NaN, as torch; no overflow below FLT_MAX)
 }
 
 // Phase-skipping switches of the timing experiments (PPGS_AMD_L32_DEBUG / PPGS_AMD_H32_DEBUG: WRONG results by

@@ -1573,7 +1573,7 @@ struct PpgStream {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool graph_steps = false;     // (measured: a replay costs MORE than the launches it replaces, profiles/r5_stream_step_graph.txt)
-    int fused_layers = 1;         // PPGS_AMD_STREAM_FUSED: 1 = one fused launch per layer for steps of >= 512 row blocks, 0 never, 2 always
+    bool fused_layers = false;    // PPGS_AMD_STREAM_FUSED=2 at creation: every step's layers as ONE fused launch each (for streams pushed in whole chunks); fixed for the life of the stream
     ~PpgStream() {
         if (e) (void)hipSetDevice(e->device);
         for (auto& kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -1599,7 +1599,7 @@ int ppg_stream_create_batch(PpgEngine* e, int batch, int max_frames, int feature
     std::unique_ptr<PpgStream> st(new PpgStream);
     st->e = e; st->batch = batch; st->cap = max_frames; st->rows = round_up(max_frames, 32); st->dtype = feature_dtype;
     st->graph_steps = ppg::env_experiment("PPGS_AMD_STREAM_GRAPH", 0) != 0;
-    st->fused_layers = std::max(0, std::min(ppg::env_switch("PPGS_AMD_STREAM_FUSED", st->fused_layers), 2));
+    st->fused_layers = ppg::env_switch("PPGS_AMD_STREAM_FUSED", 0) == 2;
     st->received.assign(batch, 0); st->x_valid.assign(batch, 0); st->o_valid.assign(batch, 0); st->finished.assign(batch, 0);
     const PpgConfig& c = e->cfg;
     const int R = st->rows, MT = batch * R;
@@ -1878,9 +1878,12 @@ int ppg_stream_push_batch(PpgStream* st, const void* chunk, int nmax, const int*
         // + the NEXT layer's Q/K/V in the token-split fused kernel the one-shot forward uses for small batches, here under
         // the step's row map.  Its workgroups stream a whole layer's weights each (no hidden splits: a split would redo
         // the out-projection) -- ~85 us per layer however few they are, so only a step of >= 512 row blocks gains
-        // (64 streams x 160 frames: 725 -> 639 us; 64 x 16: 363 -> 491 us, one stream 274 -> 432 us: four launches stay).
-        // PPGS_AMD_STREAM_FUSED=0: never, 2: always (the stream tests run green either way).
-        const bool fused = (st->fused_layers == 2 || (st->fused_layers == 1 && nmap[0] >= 512)) && e->ffn_fused && e->op_fused && e->qkv_fused && !e->split;
+        // (64 streams x 160 frames: 725 -> 639 us; 64 x 16: 363 -> 491 us, one stream 274 -> 432 us).  The form is a
+        // property of the STREAM, fixed at creation (PPGS_AMD_STREAM_FUSED=2; default: the four launches): chosen per
+        // step (round 5), a stream whose step sizes straddled the threshold computed a partially filled 16-row block
+        // with two kernels of different accumulation order -- its cached K / V rows and the later recomputed X rows then
+        // depended on the push cadence, against "a recomputed row gives the same bits wherever it lands".
+        const bool fused = st->fused_layers && e->ffn_fused && e->op_fused && e->qkv_fused && !e->split;
         for (int l = 0; l < c.num_layers; ++l) {
             const DevLayer& d = e->layers[l];
             char* qk = qk_of(l);

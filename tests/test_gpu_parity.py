@@ -1491,8 +1491,9 @@ def test_batched_kv_cached_streams_equal_causal_forward(precision, fused, monkey
     launches of the token-split kernels, one attention launch over all items' query tiles): every item equals
     the oracle's causal forward of its own utterance, with ragged, unaligned pushes per item, items that sit
     steps out, items that end at different steps and an item of one frame.  `fused`: every step's layers as ONE
-    fused launch each (out-projection + LayerNorm-1 + FFN + LayerNorm-2 + the next layer's Q/K/V under the row map --
-    what steps of >= 512 row blocks take by default, PPGS_AMD_STREAM_FUSED=2 forces it) or as four launches (=0)."""
+    fused launch each (out-projection + LayerNorm-1 + FFN + LayerNorm-2 + the next layer's Q/K/V under the row map:
+    PPGS_AMD_STREAM_FUSED=2 when the stream is created, for streams pushed in whole chunks) or as four launches (the
+    default).  The form is fixed for the life of a stream, so a row recomputed by a later step gets the same bits."""
     monkeypatch.setenv('PPGS_AMD_STREAM_FUSED', '2' if fused else '0')
     engine, state = eng(precision=precision, causal=True)
     gen = torch.Generator().manual_seed(91)

@@ -1,7 +1,7 @@
 # One gpurun call that produces every record of a round under gpurun_out/final_<tag>/ (copy what is to be judged
 # into profiles/):   bash tools/final_records.sh r5
 set -x
-tag=${1:-r5}
+tag=${1:-r6}
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/final_$tag
 mkdir -p $out
@@ -42,6 +42,9 @@ timeout 300 python tools/bench_streaming.py > $out/c5.log 2>&1; grep "^{" $out/c
 # the N-rank host path on the one GPU present (gloo; NOT a multi-GPU measurement): 8 launch loops through one GPU's queues
 PPGS_BENCH_ALIAS_GPUS=1 timeout 600 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu --no-alt > $out/alias8.log 2>&1; grep "^{" $out/alias8.log | tail -1 > $out/${tag}_bench_alias8_dry_run.json
 timeout 120 python tools/time_frontend.py > $out/time_frontend.txt 2>&1
+# the step as a timeline: which kernels of the two pipelines overlap, where a queue idles (the profiler's own per-dispatch cost included)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_tl -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-alt --steps 20 --warmup 5 --prewarm-s 0.2 > $GRAFT_REPO_ROOT/$out/prof_tl.log 2>&1 )
+python tools/step_timeline.py gpurun_out/prof_${tag}_tl 1 > $out/${tag}_step_timeline.txt 2>&1
 timeout 200 python tools/two_stream_steps.py --streams 1 2 --steps 400 > $out/two_stream_steps.txt 2>&1
 ls -la $out
 # (the merge back takes <= 64 MiB: the traces stay on the box)
