@@ -213,6 +213,16 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// The events that fork a batch's pipelines from the caller's stream and join them into it order kernels of ONE device
+// that read and write device memory: no system-scope fence (a record otherwise writes the caches back for the host and
+// for peer devices to see -- every kernel already ends with the device-scope release that makes its results visible to
+// the other XCDs, which is all the other pipeline's kernels need; a copy to the host or a collective behind the join
+// brings its own fences).  Step 0.6750 -> 0.6700 ms, four alternations of three builds on one box
+// (profiles/r6_fork_join_event_flags_ab.txt; hipEventReleaseToDevice alone: 0.6740).
+constexpr unsigned kForkJoinEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+// ... and the timing events around a launch (the profiling getters) bracket the kernel, not a cache write-back for the host
+constexpr unsigned kTimingEventFlags = hipEventDisableSystemFence;
+
 struct DevLayer {
     char* wqkv; float* bqkv;
     char* wo; float* bo;
@@ -714,7 +724,7 @@ struct Timed {
         size_t& used = e->events_used[cls];
         if (used == pool.size()) {
             EventPair p;
-            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&p.a, kTimingEventFlags) != hipSuccess || hipEventCreateWithFlags(&p.b, kTimingEventFlags) != hipSuccess) return;
             pool.push_back(p);
         }
         ev = pool[used++];
@@ -945,12 +955,12 @@ int ppg_engine_create(const PpgConfig* cfg, const PpgWeights* wts, int device, P
     e->stream_one_pass = env_experiment("PPGS_AMD_STREAM_ONE_PASS", e->stream_one_pass) != 0;
     e->stream_min_rows = std::max(1, env_experiment("PPGS_AMD_STREAMS_MIN_ROWS", e->stream_min_rows));
     e->stream_offset_us = std::max(0, env_experiment("PPGS_AMD_STREAM_OFFSET_US", e->stream_offset_us));
-    HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_fork, kForkJoinEventFlags));
     for (int i = 1; i < e->num_streams; ++i) {
         hipStream_t st;
         hipEvent_t ev;
         HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ev, kForkJoinEventFlags));
         e->side_streams.push_back(st);
         e->ev_join.push_back(ev);
     }
@@ -2330,8 +2340,8 @@ int ppg_w2v2_body_create(const PpgW2v2BodyWeights* w, int precision, int device,
 #undef NEED
     for (PpgW2v2Body::Slot& sl : m->slot) HIP_OK(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
     HIP_OK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&m->ev_fork, kForkJoinEventFlags));
+    HIP_OK(hipEventCreateWithFlags(&m->ev_join, kForkJoinEventFlags));
     m->pipelines = std::max(1, std::min(ppg::env_switch("PPGS_AMD_W2V2_STREAMS", m->pipelines), 2));
     *out = m.release();
     return PPG_OK;
@@ -2592,8 +2602,8 @@ int ppg_frontend(int device, const float* audio, int batch, int samples, void* s
     if (f->profiling) {
         if (f->events_used == f->events.size()) {
             EventPair p;
-            HIP_OK(hipEventCreate(&p.a));
-            HIP_OK(hipEventCreate(&p.b));
+            HIP_OK(hipEventCreateWithFlags(&p.a, kTimingEventFlags));
+            HIP_OK(hipEventCreateWithFlags(&p.b, kTimingEventFlags));
             f->events.push_back(p);
         }
         ev = f->events[f->events_used++];
@@ -2645,7 +2655,7 @@ int ppg_engine_profile(PpgEngine* e, int enable) {
         if (!(e->profiling & (1u << cls))) continue;
         while (e->events[cls].size() < 32) {
             EventPair p;
-            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) break;
+            if (hipEventCreateWithFlags(&p.a, kTimingEventFlags) != hipSuccess || hipEventCreateWithFlags(&p.b, kTimingEventFlags) != hipSuccess) break;
             e->events[cls].push_back(p);
         }
     }
