@@ -717,8 +717,8 @@ int get_plan(PpgEngine* e, int batch, int frames, const int64_t* lengths, int le
 
 struct Timed {
     PpgEngine* e; int cls; hipStream_t s; EventPair ev{}; bool on = false;
-    Timed(PpgEngine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
-        if (!(e->profiling & (1u << cls))) return;
+    Timed(PpgEngine* e_, int cls_, hipStream_t s_, bool live = true) : e(e_), cls(cls_), s(s_) {
+        if (!live || !(e->profiling & (1u << cls))) return;
         if (e->launch_seq[cls]++ % (size_t)e->profile_stride) return;
         auto& pool = e->events[cls];
         size_t& used = e->events_used[cls];
@@ -1299,14 +1299,21 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         return fail(PPG_EWORKSPACE, "workspace %zu bytes < required %zu", workspace_bytes, plan.info.workspace_bytes);
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(PPG_EINVAL, "workspace not 256-byte aligned");
 
+    // (a launch outside the segment a call of run_group is asked for is skipped: see `live` there)
 #define LAUNCH_OK(expr, what)                                                        \
     do {                                                                             \
-        hipError_t he_ = (expr);                                                     \
-        if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
+        if (live) {                                                                  \
+            hipError_t he_ = (expr);                                                 \
+            if (he_ != hipSuccess) return fail(PPG_EDEVICE, "%s: %s", what, hipGetErrorString(he_)); \
+        }                                                                            \
     } while (0)
 
-    // one independent pipeline per plan group, each on its own stream
-    auto run_group = [&](const PlanGroup& grp, hipStream_t s) -> int {
+    // one independent pipeline per plan group, each on its own stream.  The launch sequence of a group comes in SEGMENTS
+    // -- 0: the head (gather, input convolution, layer 0's Q/K/V), 1 + l: layer l, 1 + layers: the output convolution --
+    // and a call enqueues one of them (seg < 0: all): the groups' segments are enqueued alternately below.
+    const int nseg = c.num_layers + 2;
+    auto run_group = [&](const PlanGroup& grp, hipStream_t s, const int seg) -> int {
+    bool live = seg < 0 || seg == 0;
     const int M = grp.tokens;
     const Workspace ws = layout(e, grp.tokens, grp.vt_tokens);
     char* base = static_cast<char*>(workspace) + grp.ws_offset;
@@ -1334,7 +1341,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     const bool sub32 = use32 && e->subtile && H == 256 && (F / 128) % 2 == 0 && 3 * tiles32 <= e->num_cus;
     const bool head = use32 && e->head32 && (2 * tiles32 >= e->num_cus || sub32);
     if (head) {
-        Timed t(e, PPG_K_INCONV, s);
+        Timed t(e, PPG_K_INCONV, s, live);
         Head32Args a{};
         a.feats = features; a.dtype = feature_dtype; a.C = c.input_channels; a.T = frames; a.overlap = c.chunk_overlap;
         a.win_img = e->win_img; a.b_in = e->b_in; a.pe = e->pe; a.X = X;
@@ -1350,7 +1357,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         LAUNCH_OK(ppg::launch_head32(prec, a, s), "head32");
     }
     if (!head) {
-        Timed t(e, PPG_K_GATHER, s);
+        Timed t(e, PPG_K_GATHER, s, live);
         GatherArgs g{};
         g.feats = features; g.dtype = feature_dtype; g.C = c.input_channels; g.T = frames;
         g.overlap = c.chunk_overlap; g.xw = xw; g.Cp = e->Cp;
@@ -1368,7 +1375,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         return a;
     };
     if (!head) {
-        Timed t(e, PPG_K_INCONV, s);
+        Timed t(e, PPG_K_INCONV, s, live);
         LinearArgs a = base_args();
         a.x_tiled = use32 ? (e->x16 ? 2 : 1) : 0;
         a.act = xw; a.lda_bytes = e->Cp * e->sz; a.taps = 5;
@@ -1382,8 +1389,9 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
     bool qkv_done = head;    // this layer's Q/K/V came out of the previous layer's FFN kernel (layer 0's: out of the head kernel)
     for (int l = 0; l < c.num_layers; ++l) {
         const DevLayer& d = e->layers[l];
+        live = seg < 0 || seg == 1 + l;
         if (!qkv_done) {
-            Timed t(e, PPG_K_QKV, s);
+            Timed t(e, PPG_K_QKV, s, live);
             LinearArgs a = base_args();
             a.act = act_x; a.lda_bytes = H * e->sz;
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
@@ -1393,7 +1401,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             LAUNCH_OK(ppg::launch_linear(prec, EPI_QKV, 16, lnt, a, 3 * H / 256, s), "qkv");
         }
         {
-            Timed t(e, PPG_K_ATTENTION, s);
+            Timed t(e, PPG_K_ATTENTION, s, live);
             AttnArgs a{};
             a.qk = qk; a.qk_ld_bytes = 2 * H * e->sz; a.vt = vt; a.vt_ld_bytes = ws.vt_ld * e->sz;
             a.ao = ao; a.H = H; a.causal = c.is_causal;
@@ -1402,7 +1410,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             LAUNCH_OK(ppg::launch_attn(prec, a, (int)grp.items.size(), c.heads, e->head_dim, s), "attention");
         }
         if (use32) {
-            Timed t(e, PPG_K_FFN, s);
+            Timed t(e, PPG_K_FFN, s, live);
             Layer32Args a{};
             a.ao = ao; a.wo_img = d.wo_img; a.w1_img = d.w1_img; a.w2_img = d.w2_img;
             a.bo = d.bo; a.g1 = d.g1; a.e1 = d.e1; a.b1 = d.b1; a.b2 = d.b2; a.g2 = d.g2; a.e2 = d.e2;
@@ -1424,7 +1432,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         const bool fuse_op = e->ffn_fused && e->op_fused && ws.ffn_splits == 1;
         const bool x2_layer = e->split && e->ffn32x2 > 0 && d.w1x_img && 2 * ((M + ppg::ffn32x2_tokens() - 1) / ppg::ffn32x2_tokens()) >= e->num_cus;
         if (!fuse_op && !(x2_layer && e->ffn32x2 >= 2)) {
-            Timed t(e, PPG_K_OUTPROJ_LN, s);
+            Timed t(e, PPG_K_OUTPROJ_LN, s, live);
             LinearArgs a = base_args();
             a.act = ao; a.lda_bytes = H * e->sz;
             a.groups_per_tap = hg; a.real_groups = hg; a.total_groups = hg;
@@ -1433,7 +1441,7 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             LAUNCH_OK(ppg::launch_linear(prec, EPI_RESLN, H / 16, lnt_ln, a, 1, s), "out-proj+LN");
         }
         {
-            Timed t(e, PPG_K_FFN, s);
+            Timed t(e, PPG_K_FFN, s, live);
             if (x2_layer) {
                 Ffn32X2Args a{};
                 a.xb = Xb; a.X = X; a.xb_out = Xb; a.w1_img = d.w1x_img; a.w2_img = d.w2x_img;
@@ -1477,8 +1485,9 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
             }
         }
     }
+    live = seg < 0 || seg == 1 + c.num_layers;
     {
-        Timed t(e, PPG_K_OUTCONV_SOFTMAX, s);
+        Timed t(e, PPG_K_OUTCONV_SOFTMAX, s, live);
         LinearArgs a = base_args();
         a.act = act_x; a.lda_bytes = H * e->sz; a.taps = 5;
         a.groups_per_tap = e->out_groups_per_tap; a.real_groups = 5 * e->out_groups_per_tap;
@@ -1500,11 +1509,22 @@ int ppg_encode(PpgEngine* e, const void* features, int feature_dtype, const int6
         HIP_OK(hipStreamWaitEvent(side, e->ev_fork, 0));
         if (e->stream_offset_us > 0)
             hipLaunchKernelGGL(phase_delay_kernel, dim3(1), dim3(64), 0, side, (unsigned long long)(100ull * e->stream_offset_us * gi));
-        if ((rc = run_group(plan.groups[gi], side))) return rc;
-        HIP_OK(hipEventRecord(e->ev_join[gi - 1], side));
     }
-    if ((rc = run_group(plan.groups[0], s))) return rc;
-    for (size_t gi = 1; gi < ngroups; ++gi) HIP_OK(hipStreamWaitEvent(s, e->ev_join[gi - 1], 0));
+    // The pipelines' launches are enqueued segment by segment, alternately: enqueued one whole pipeline after the
+    // other, the second one's first kernel reached its queue ~50 us (a dozen launches) behind the first one's -- nothing
+    // in a loop of steps, where the host runs ahead of the device, but the first step of a short timed block (and a
+    // latency-bound caller's only step) started one pipeline that much late (tools/block_overhead.py).
+    if (ngroups == 1) {
+        if ((rc = run_group(plan.groups[0], s, -1))) return rc;
+    } else {
+        for (int seg = 0; seg < nseg; ++seg)
+            for (size_t gi = 0; gi < ngroups; ++gi)
+                if ((rc = run_group(plan.groups[gi], gi == 0 ? s : e->side_streams[gi - 1], seg))) return rc;
+    }
+    for (size_t gi = 1; gi < ngroups; ++gi) {
+        HIP_OK(hipEventRecord(e->ev_join[gi - 1], e->side_streams[gi - 1]));
+        HIP_OK(hipStreamWaitEvent(s, e->ev_join[gi - 1], 0));
+    }
 #undef LAUNCH_OK
     return PPG_OK;
 }
