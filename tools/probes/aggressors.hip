@@ -1,5 +1,5 @@
 // Synthetic "aggressor" kernels for the co-residency forensics: round 2's 256-thread mel frontend
-// (-DPPG_FE_R2 build) computes a frame pair wrong about once per 300 pairs when an attention kernel's workgroup
+// (one 256-thread team per workgroup; the build was removed in round 6) computed a frame pair wrong about once per 300 pairs when an attention kernel's workgroup
 // shares its CU.  Which INGREDIENT of an attention kernel does it?  Every kernel here is one 256-thread workgroup
 // shape with a caller-chosen amount of dynamic LDS (so that it fits beside one 79.5 KiB frontend workgroup) that
 // spins on a mix of instruction classes selected by a bit mask:
@@ -8,7 +8,7 @@
 //   64 plain v_fma_f32                       128 global loads (L2 resident)    256 global -> LDS DMA
 //  512 v_sqrt_f32 / v_rcp_f32 / v_log_f32   1024 v_fma_f64                   2048 s_setprio 3 around the loop
 //  4096 v_mfma_f32_32x32x16_bf16            8192 workgroup barriers
-// Built by tools/probes/build.sh into tools/bin/libaggressors.so, driven by tools/coresidency_matrix.py.
+// Built by tools/probes/build.sh into tools/bin/libaggressors.so, driven by tests/test_gpu_soak.py (and, until round 6, tools/coresidency_matrix.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

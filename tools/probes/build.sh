@@ -3,7 +3,7 @@
 #   libaggressors.so                 synthetic aggressor / victim kernels (tools/probes/aggressors.hip)
 #   mfma_clock_probe                 dense-MFMA clock / delivered-peak probe (tools/probes/mfma_clock_probe.hip; bench.py reports it)
 #   libppgs_amd_<variant>.so         the product library with ONLY ppg_frontend.hip rebuilt with other flags
-# usage: tools/probes/build.sh [variant "flags" ...]      e.g.  r2 "-DPPG_FE_R2"  r2_O1 "-DPPG_FE_R2 -O1"
+# usage: tools/probes/build.sh [variant "flags" ...]      e.g.  timing "-DPPG_FE_TIMING"  o1 "-O1"
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 CSRC=$ROOT/ppgs_amd/csrc
